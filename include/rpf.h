@@ -1,0 +1,215 @@
+/*
+ * rpf.h — C ABI of the MI355X-native RAW development / edit hot path.
+ *
+ * Drop-in boundary for the operator surface of the reference's `photo-editor`
+ * crate (all citations relative to /root/reference):
+ *
+ *   rpf_processor_*            GpuProcessor::new / get_adapter_string_list
+ *                              rust/photo-editor/src/gpu_image_processing.rs:43-200, 412-426
+ *   rpf_editor_create_from_rgb_f32
+ *                              PhotoEditor::new_from_rgb_f32   rust/photo-editor/src/lib.rs:125-166
+ *   rpf_editor_create_from_bayer_u16
+ *                              the RAW ingest the Godot-legacy crate delegates to rawler
+ *                              rust-godot-legacy/photo-editor/src/image.rs:509-557 (arithmetic NOT in the
+ *                              reference source; this build's own front half)
+ *   rpf_set_whitebalance       PhotoEditor::set_whitebalance               lib.rs:255-265
+ *   rpf_set_vignette           PhotoEditor::set_vignette                   lib.rs:267-270
+ *   rpf_set_lens_distortion_correction
+ *                              PhotoEditor::set_lens_distortion_correction lib.rs:272-275
+ *   rpf_set_tone               PhotoEditor::set_tone                       lib.rs:278-298
+ *   rpf_set_brightness_tone_curve / rpf_set_oklch_{hue,saturation,lightness}_curve
+ *                              PhotoEditor::set_*_curve                    lib.rs:300-479
+ *   rpf_add_mask / rpf_remove_mask / rpf_reset
+ *                              lib.rs:481-505, 227-235
+ *   rpf_apply_adjustments      PhotoEditor::apply_adjustments -> GpuProcessor::apply_adjustments -> wgsl main
+ *                              lib.rs:507-515, gpu_image_processing.rs:214-400, wgpu_shader.wgsl:265-337
+ *   rpf_get_rgb_f32 / rpf_get_rgba_f32 / rpf_get_rgb_u8
+ *                              Image::to_flat_vec_rgb / to_flat_vec_rgba / to_u8_rgbimage
+ *                              rust/photo-editor/src/image.rs:202-358, 375-383
+ *   rpf_pchip_interpolate_i32  interpolation::pchip_interpolate            interpolation.rs:11-123
+ *
+ * plus a device-pointer layer (rpf_dev_*) used by the benchmark harness and by the
+ * row-tile sharding across GPUs: the caller owns device memory (e.g. a torch
+ * tensor) and the library only launches kernels on it.
+ *
+ * Conventions
+ *   - every function returns an rpf_status (0 = OK); rpf_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.  Nothing
+ *     throws or aborts across this boundary.
+ *   - host pointers are borrowed for the duration of the call only.
+ *   - an editor is externally synchronised (one thread at a time, like `&mut self`);
+ *     a processor may be shared by several editors and must outlive them.
+ *   - rpf_apply_adjustments enqueues on the editor's HIP stream and returns;
+ *     rpf_get_* / rpf_editor_sync wait (reference: submit returns before the GPU
+ *     finishes, readback blocks; gpu_image_processing.rs:391-399, image.rs:249-259).
+ *   - there is NO CPU fallback: without a usable HIP device rpf_processor_create
+ *     fails with RPF_ERR_GPU_INITIALIZATION and nothing can be computed.
+ */
+#ifndef RPF_H
+#define RPF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPF_CURVE_RESOLUTION 65536 /* lib.rs:17 */
+#define RPF_MAX_MASKS 8            /* "main" + 7 user masks per editor */
+
+typedef enum rpf_status {
+    RPF_OK = 0,
+    /* PhotoEditorError, errors.rs:7-49 */
+    RPF_ERR_FAILED_TO_READ_IMAGE = 1,
+    RPF_ERR_FAILED_TO_SAVE_IMAGE = 2,
+    RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT = 3,
+    RPF_ERR_SAVE_IMAGE_UNSUPPORTED_FORMAT = 4,
+    RPF_ERR_GPU_COMPUTE = 5,
+    RPF_ERR_GPU_INITIALIZATION = 6,
+    RPF_ERR_MASK_NOT_FOUND = 7,
+    /* InterpolationError, errors.rs:105-130 (wrapped by PhotoEditorError::Interpolation) */
+    RPF_ERR_INTERP_MISMATCHED_LENGTHS = 16,
+    RPF_ERR_INTERP_NOT_ENOUGH_POINTS = 17,
+    RPF_ERR_INTERP_NOT_STRICTLY_INCREASING = 18,
+    RPF_ERR_INTERP_MISSING_CURVE_OR_CONTROL_POINTS = 19,
+    RPF_ERR_INTERP_INVALID_CURVE_LENGTH = 20,
+    RPF_ERR_INTERP_MISSING_CONTROL_POINTS = 21,
+    RPF_ERR_INTERP_EMPTY_CONTROL_POINTS = 22,
+    /* this ABI's own */
+    RPF_ERR_INVALID_ARGUMENT = 32,
+    RPF_ERR_TOO_MANY_MASKS = 33
+} rpf_status;
+
+typedef struct rpf_processor rpf_processor;
+typedef struct rpf_editor rpf_editor;
+
+/* CFA layouts: colour of (even row, even column), then its row neighbour. */
+enum { RPF_CFA_RGGB = 0, RPF_CFA_BGGR = 1, RPF_CFA_GRBG = 2, RPF_CFA_GBRG = 3 };
+
+/* RAW front-half parameters.  black/wb are indexed by RGGB cell position
+ * R, G(red row), G(blue row), B.  cam2rgb is row major: out_i = sum_j cam2rgb[3i+j] cam_j. */
+typedef struct rpf_raw_params {
+    uint32_t cfa_pattern;
+    float black[4];
+    float white;
+    float wb[4];
+    float cam2rgb[9];
+} rpf_raw_params;
+
+/* GpuEditParameters, gpu_image_processing.rs:18-32 (introspection only) */
+typedef struct rpf_gpu_edit_parameters {
+    float r_gain, g_gain, b_gain;
+    float vignette, lens_distortion;
+    float exposure, contrast, shadow, highlight, black, white;
+} rpf_gpu_edit_parameters;
+
+/* Which curve, for rpf_editor_get_curve */
+enum { RPF_CURVE_BRIGHTNESS = 0, RPF_CURVE_HUE = 1, RPF_CURVE_SATURATION = 2, RPF_CURVE_LIGHTNESS = 3 };
+
+/* Output of the device-pointer layer */
+enum { RPF_OUT_RGBA_F32 = 0, RPF_OUT_RGB_F32 = 1, RPF_OUT_RGB_U8 = 2 };
+
+const char* rpf_last_error(void);
+const char* rpf_version(void);
+
+/* ---- processor: GpuProcessor ------------------------------------------------------------ */
+int rpf_device_count(int* count);
+int rpf_device_name(int device, char* buf, size_t buf_len); /* get_adapter_string_list */
+int rpf_processor_create(int device, rpf_processor** out);  /* GpuProcessor::new(adapter_index) */
+void rpf_processor_destroy(rpf_processor* p);
+int rpf_processor_device(const rpf_processor* p, int* device);
+int rpf_processor_compute_units(const rpf_processor* p, int* cus);
+
+/* ---- editor: PhotoEditor ----------------------------------------------------------------- */
+/* Interleaved RGB f32, row major, top-left origin, width*height*3 values (note: the Rust
+ * signature is (vec, height, width); the wasm wrapper is (data, width, height) — this ABI
+ * follows the wasm order). */
+int rpf_editor_create_from_rgb_f32(rpf_processor* p, const float* rgb, uint32_t width, uint32_t height,
+                                   rpf_editor** out);
+/* u16 Bayer plane, pitch = width.  The editor keeps the CFA on the device; apply runs the
+ * fused demosaic -> ... -> gamma kernel. */
+int rpf_editor_create_from_bayer_u16(rpf_processor* p, const uint16_t* cfa, uint32_t width, uint32_t height,
+                                     const rpf_raw_params* raw, rpf_editor** out);
+/* Operator state only (setters, curves, masks bookkeeping) with no device: for exercising the
+ * state machine where no GPU exists.  apply / get_* fail with RPF_ERR_GPU_COMPUTE. */
+int rpf_editor_create_headless(uint32_t width, uint32_t height, rpf_editor** out);
+void rpf_editor_destroy(rpf_editor* e);
+
+int rpf_width(const rpf_editor* e, uint32_t* width);
+int rpf_height(const rpf_editor* e, uint32_t* height);
+
+/* mask_name NULL = "main" (Option<&str> None) */
+int rpf_set_whitebalance(rpf_editor* e, int32_t temperature, int32_t tint, const char* mask_name);
+int rpf_set_vignette(rpf_editor* e, int32_t value);
+int rpf_set_lens_distortion_correction(rpf_editor* e, int32_t value);
+int rpf_set_tone(rpf_editor* e, float exposure, int32_t contrast, int32_t shadow, int32_t highlight, int32_t black,
+                 int32_t white, const char* mask_name);
+
+/* curve: NULL or curve_len values (must be 65536).  xs / ys: NULL or n_x / n_y control points. */
+int rpf_set_brightness_tone_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs,
+                                  size_t n_x, const int32_t* ys, size_t n_y, const char* mask_name);
+int rpf_set_oklch_hue_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs, size_t n_x,
+                            const int32_t* ys, size_t n_y, const char* mask_name);
+int rpf_set_oklch_saturation_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs,
+                                   size_t n_x, const int32_t* ys, size_t n_y, const char* mask_name);
+int rpf_set_oklch_lightness_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs,
+                                  size_t n_x, const int32_t* ys, size_t n_y, const char* mask_name);
+
+/* mask: height*width f32, binarised v >= main.mask_range ? 1 : 0 (lib.rs:481-487) */
+int rpf_add_mask(rpf_editor* e, const char* name, const float* mask);
+int rpf_remove_mask(rpf_editor* e, const char* name); /* "main" is kept (lib.rs:501-505) */
+int rpf_set_mask_range(rpf_editor* e, float mask_range); /* EditParameters.mask_range is a pub field */
+int rpf_reset(rpf_editor* e);
+int rpf_num_masks(const rpf_editor* e, uint32_t* n);
+
+int rpf_apply_adjustments(rpf_editor* e);
+int rpf_editor_sync(rpf_editor* e);
+
+/* Readback of the current image (the original until the first apply, like PhotoEditor.image). */
+int rpf_get_rgba_f32(rpf_editor* e, float* out); /* width*height*4 */
+int rpf_get_rgb_f32(rpf_editor* e, float* out);  /* width*height*3 */
+int rpf_get_rgb_u8(rpf_editor* e, uint8_t* out); /* (v.clamp(0,1)*255) as u8, image.rs:375-383 */
+
+/* Introspection used by the parity tests */
+int rpf_editor_get_gpu_params(const rpf_editor* e, const char* mask_name, rpf_gpu_edit_parameters* out);
+int rpf_editor_get_curve(const rpf_editor* e, int which, const char* mask_name, int32_t* out65536);
+
+/* ---- stateless host helpers --------------------------------------------------------------- */
+/* interpolation.rs:11-123 on i32 arrays; bad_index receives the index for NOT_STRICTLY_INCREASING. */
+int rpf_pchip_interpolate_i32(const int32_t* x_pts, size_t n_x, const int32_t* y_pts, size_t n_y,
+                              const int32_t* x_eval, size_t n_eval, int32_t* y_eval, int32_t* bad_index);
+
+/* ---- device-pointer layer ------------------------------------------------------------------
+ * Row tiles: a frame of frame_width x frame_height is cut into bands of rows [y0, y0+rows).
+ * d_cfa points at a (rows + 4) x frame_width u16 buffer whose row r holds frame row y0 - 2 + r
+ * (two halo rows above and below the band).  Halo rows outside the frame are never read: the
+ * frame edge is mirrored (reflect-101) inside the kernel.  y0 and rows need not be even.
+ * d_out: rows x frame_width pixels in `out_format`.  stream: a hipStream_t (NULL = default).
+ */
+typedef struct rpf_tile {
+    uint32_t frame_width, frame_height;
+    uint32_t y0, rows;
+} rpf_tile;
+
+/* black level -> WB -> 5x5 demosaic -> camera matrix; linear RGBA32F out */
+int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_params* raw, const rpf_tile* tile,
+                     float* d_rgba_out, void* stream);
+/* fused RAW -> display chain with the editor's current edit state (masks/curves/params).
+ * The editor must have been created for the tile's size (rows x frame_width) or headless-with-device
+ * via rpf_editor_create_for_tile. */
+int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* raw, void* d_out, int out_format,
+                    void* stream);
+/* the reference-equivalent back half: RGBA32F tile in -> out (wgsl main) */
+int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_format, void* stream);
+
+/* An editor that owns edit state + device LUTs/masks for a row tile but no image. */
+int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_editor** out);
+
+/* Kernel variant selection for A/B measurements (bench.py --variant); 0 = default. */
+int rpf_set_kernel_variant(rpf_processor* p, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPF_H */

@@ -1,0 +1,14 @@
+"""rawphotoforge_amd — MI355X-native RAW development / edit hot path (gfx950 HIP kernels behind a C ABI).
+
+The product is ``librpf_hip.so`` (``include/rpf.h``); this package is its ctypes mirror of the
+reference's ``photo-editor`` operator surface plus the row-tile sharding helpers.  Importing the
+package never touches the GPU; the first call into the library does.  There is no CPU fallback.
+"""
+from ._native import (CFA_BGGR, CFA_GBRG, CFA_GRBG, CFA_RGGB, CURVE_BRIGHTNESS, CURVE_HUE, CURVE_LIGHTNESS,
+                      CURVE_RESOLUTION, CURVE_SATURATION, MAX_MASKS, OUT_RGB_F32, OUT_RGB_U8, OUT_RGBA_F32)
+from .editor import (EmptyControlPoints, FailedToReadImage, GpuComputeError, GpuInitializationError, GpuProcessor,
+                     InterpolationError, InvalidArgument, InvalidCurveLength, MaskNotFound, MismatchedLengths,
+                     MissingControlPoints, MissingCurveOrControlPoints, NotEnoughPoints, NotStrictlyIncreasing,
+                     PhotoEditor, PhotoEditorError, RawParams, TooManyMasks, dev_demosaic, pchip_interpolate)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,124 @@
+"""ctypes binding of librpf_hip.so (include/rpf.h).  Fails loudly when the HIP library is
+missing: there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librpf_hip.so")
+
+CURVE_RESOLUTION = 65536
+MAX_MASKS = 8
+
+# rpf_status
+OK = 0
+ERR_FAILED_TO_READ_IMAGE = 1
+ERR_FAILED_TO_SAVE_IMAGE = 2
+ERR_READ_IMAGE_UNSUPPORTED_FORMAT = 3
+ERR_SAVE_IMAGE_UNSUPPORTED_FORMAT = 4
+ERR_GPU_COMPUTE = 5
+ERR_GPU_INITIALIZATION = 6
+ERR_MASK_NOT_FOUND = 7
+ERR_INTERP_MISMATCHED_LENGTHS = 16
+ERR_INTERP_NOT_ENOUGH_POINTS = 17
+ERR_INTERP_NOT_STRICTLY_INCREASING = 18
+ERR_INTERP_MISSING_CURVE_OR_CONTROL_POINTS = 19
+ERR_INTERP_INVALID_CURVE_LENGTH = 20
+ERR_INTERP_MISSING_CONTROL_POINTS = 21
+ERR_INTERP_EMPTY_CONTROL_POINTS = 22
+ERR_INVALID_ARGUMENT = 32
+ERR_TOO_MANY_MASKS = 33
+
+OUT_RGBA_F32, OUT_RGB_F32, OUT_RGB_U8 = 0, 1, 2
+CFA_RGGB, CFA_BGGR, CFA_GRBG, CFA_GBRG = 0, 1, 2, 3
+CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
+
+
+class RawParams(C.Structure):
+    """rpf_raw_params"""
+    _fields_ = [("cfa_pattern", C.c_uint32), ("black", C.c_float * 4), ("white", C.c_float),
+                ("wb", C.c_float * 4), ("cam2rgb", C.c_float * 9)]
+
+
+class GpuEditParameters(C.Structure):
+    """rpf_gpu_edit_parameters == GpuEditParameters (gpu_image_processing.rs:18-32)"""
+    _fields_ = [(n, C.c_float) for n in ("r_gain", "g_gain", "b_gain", "vignette", "lens_distortion", "exposure",
+                                         "contrast", "shadow", "highlight", "black", "white")]
+
+
+class Tile(C.Structure):
+    """rpf_tile"""
+    _fields_ = [("frame_width", C.c_uint32), ("frame_height", C.c_uint32), ("y0", C.c_uint32), ("rows", C.c_uint32)]
+
+
+# every symbol include/rpf.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+_vp, _sz, _i32p, _f32p, _cs = C.c_void_p, C.c_size_t, _P(C.c_int32), _P(C.c_float), C.c_char_p
+_curve_args = [_vp, _i32p, _sz, _i32p, _sz, _i32p, _sz, _cs]
+SYMBOLS = {
+    "rpf_last_error": (C.c_char_p, []),
+    "rpf_version": (C.c_char_p, []),
+    "rpf_device_count": (C.c_int, [_P(C.c_int)]),
+    "rpf_device_name": (C.c_int, [C.c_int, C.c_char_p, _sz]),
+    "rpf_processor_create": (C.c_int, [C.c_int, _P(_vp)]),
+    "rpf_processor_destroy": (None, [_vp]),
+    "rpf_processor_device": (C.c_int, [_vp, _P(C.c_int)]),
+    "rpf_processor_compute_units": (C.c_int, [_vp, _P(C.c_int)]),
+    "rpf_editor_create_from_rgb_f32": (C.c_int, [_vp, _f32p, C.c_uint32, C.c_uint32, _P(_vp)]),
+    "rpf_editor_create_from_bayer_u16": (C.c_int, [_vp, _P(C.c_uint16), C.c_uint32, C.c_uint32, _P(RawParams),
+                                                   _P(_vp)]),
+    "rpf_editor_create_headless": (C.c_int, [C.c_uint32, C.c_uint32, _P(_vp)]),
+    "rpf_editor_create_for_tile": (C.c_int, [_vp, _P(Tile), _P(_vp)]),
+    "rpf_editor_destroy": (None, [_vp]),
+    "rpf_width": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "rpf_height": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "rpf_set_whitebalance": (C.c_int, [_vp, C.c_int32, C.c_int32, _cs]),
+    "rpf_set_vignette": (C.c_int, [_vp, C.c_int32]),
+    "rpf_set_lens_distortion_correction": (C.c_int, [_vp, C.c_int32]),
+    "rpf_set_tone": (C.c_int, [_vp, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _cs]),
+    "rpf_set_brightness_tone_curve": (C.c_int, _curve_args),
+    "rpf_set_oklch_hue_curve": (C.c_int, _curve_args),
+    "rpf_set_oklch_saturation_curve": (C.c_int, _curve_args),
+    "rpf_set_oklch_lightness_curve": (C.c_int, _curve_args),
+    "rpf_add_mask": (C.c_int, [_vp, _cs, _f32p]),
+    "rpf_remove_mask": (C.c_int, [_vp, _cs]),
+    "rpf_set_mask_range": (C.c_int, [_vp, C.c_float]),
+    "rpf_reset": (C.c_int, [_vp]),
+    "rpf_num_masks": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "rpf_apply_adjustments": (C.c_int, [_vp]),
+    "rpf_editor_sync": (C.c_int, [_vp]),
+    "rpf_get_rgba_f32": (C.c_int, [_vp, _f32p]),
+    "rpf_get_rgb_f32": (C.c_int, [_vp, _f32p]),
+    "rpf_get_rgb_u8": (C.c_int, [_vp, _P(C.c_uint8)]),
+    "rpf_editor_get_gpu_params": (C.c_int, [_vp, _cs, _P(GpuEditParameters)]),
+    "rpf_editor_get_curve": (C.c_int, [_vp, C.c_int, _cs, _i32p]),
+    "rpf_pchip_interpolate_i32": (C.c_int, [_i32p, _sz, _i32p, _sz, _i32p, _sz, _i32p, _i32p]),
+    "rpf_dev_demosaic": (C.c_int, [_vp, _vp, _P(RawParams), _P(Tile), _vp, _vp]),
+    "rpf_dev_develop": (C.c_int, [_vp, _vp, _P(RawParams), _vp, C.c_int, _vp]),
+    "rpf_dev_apply": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "rpf_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librpf_hip.so; raise if it was not built (python -m rawphotoforge_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built and there is no CPU fallback. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` or `python rawphotoforge_amd/build.py`.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError here = header/library drift: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    return lib().rpf_last_error().decode("utf-8", "replace")

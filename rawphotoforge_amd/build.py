@@ -1,0 +1,47 @@
+"""Build rawphotoforge_amd/librpf_hip.so (gfx950 kernels + the extern "C" boundary) in-tree.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the parity contract: the
+oracle rounds after every binary32 operation (oracle/rpf_oracle.c), so must the kernels and
+the host-side f32 arithmetic (PCHIP, parameter conversion).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librpf_hip.so")
+SOURCES = ["rpf_kernels.hip", "rpf_api.cpp", "rpf_tables.cpp"]
+HEADERS = ["rpf_math.h", "rpf_chain.h", "rpf_host.h", "rpf_launch.h", os.path.join("..", "..", "include", "rpf.h")]
+ARCH = "gfx950"
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+               "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,586 @@
+// rpf_api.cpp — the extern "C" boundary (include/rpf.h): GpuProcessor / PhotoEditor of the
+// reference's photo-editor crate (rust/photo-editor/src/lib.rs, gpu_image_processing.rs,
+// image.rs) re-stated over HIP.  No torch, no CPU compute path: every pixel is produced by
+// the gfx950 kernels in rpf_kernels.hip or not at all.
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rpf_host.h"
+#include "rpf_launch.h"
+
+namespace rpf { void build_math_tables(MathTables& T); }
+
+using namespace rpf;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+static int fail(const Status& st) { return fail(st.code, st.msg); }
+static int ok()
+{
+    return RPF_OK;
+}
+static int hip_fail(hipError_t e, const char* what, int code = RPF_ERR_GPU_COMPUTE)
+{
+    // errors.rs:35-39 "GPU compute error" / :41-45 "GPU initialization error"
+    return fail(code, std::string(code == RPF_ERR_GPU_INITIALIZATION ? "GPU initialization error: "
+                                                                      : "GPU compute error: ") +
+                          what + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);    \
+    } while (0)
+
+struct rpf_processor {
+    int device = 0;
+    int num_cus = 0;
+    int variant = 0;
+    MathTables* d_tabs = nullptr;
+    std::atomic<int> editors{0};
+};
+
+struct rpf_editor {
+    rpf_processor* proc = nullptr;  // null: headless (state only)
+    EditState state;
+    TileGeom geom{};
+    bool owns_image = false;      // created from host pixels (vs. for_tile)
+    bool is_bayer = false;
+    RawParamsDev raw{};
+    uint16_t* d_cfa = nullptr;    // (rows + 4) x width, rows 0,1 and rows+2,rows+3 are halo
+    float* d_original = nullptr;  // RGBA32F linear (rgb editors; bayer editors: demosaic cache)
+    bool original_valid = false;
+    float* d_image = nullptr;     // RGBA32F result of the last apply
+    bool image_valid = false;
+    void* d_scratch = nullptr;    // readback repack
+    size_t scratch_bytes = 0;
+    // device copy of the edit state
+    uint16_t* d_bright = nullptr;
+    ushort4* d_hsl = nullptr;
+    uint8_t* d_masks = nullptr;
+    uint32_t lut_capacity = 0;    // masks worth of LUT storage
+    uint32_t mask_capacity = 0;   // user-mask planes allocated
+    uint64_t uploaded_params = 0, uploaded_masks = 0;
+    DeviceEdit dev{};
+    hipStream_t stream = nullptr;
+
+    rpf_editor(uint32_t w, uint32_t h) : state(w, h) {}
+};
+
+static LaunchCfg cfg_of(const rpf_processor* p) { return LaunchCfg{p->num_cus, p->variant}; }
+
+static size_t npix_of(const rpf_editor* e) { return (size_t)e->geom.rows * e->geom.width; }
+
+// Refresh the device copy of params / curves / masks if a setter ran since the last upload.
+static int sync_edit_state(rpf_editor* e)
+{
+    const uint32_t n = (uint32_t)e->state.masks.size();
+    if (e->uploaded_params != e->state.params_version) {
+        if (e->lut_capacity < n) {
+            if (e->d_bright) HIP_TRY(hipFree(e->d_bright));
+            if (e->d_hsl) HIP_TRY(hipFree(e->d_hsl));
+            e->d_bright = nullptr; e->d_hsl = nullptr;
+            HIP_TRY(hipMalloc((void**)&e->d_bright, (size_t)n * RPF_CURVE_RESOLUTION * sizeof(uint16_t)));
+            HIP_TRY(hipMalloc((void**)&e->d_hsl, (size_t)n * RPF_CURVE_RESOLUTION * sizeof(ushort4)));
+            e->lut_capacity = n;
+        }
+        std::vector<uint16_t> bright((size_t)n * RPF_CURVE_RESOLUTION);
+        std::vector<ushort4> hsl((size_t)n * RPF_CURVE_RESOLUTION);
+        for (uint32_t m = 0; m < n; ++m) {
+            const EditParameters& p = e->state.masks[m].params;
+            e->dev.mp[m] = make_mask_params(p);
+            for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) {
+                const size_t k = (size_t)m * RPF_CURVE_RESOLUTION + i;
+                bright[k] = (uint16_t)lut_clamp(p.curve[RPF_CURVE_BRIGHTNESS][i]);  // wgsl:188
+                hsl[k].x = (uint16_t)lut_clamp(p.curve[RPF_CURVE_HUE][i]);
+                hsl[k].y = (uint16_t)lut_clamp(p.curve[RPF_CURVE_SATURATION][i]);
+                hsl[k].z = (uint16_t)lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][i]);
+                hsl[k].w = 0;
+            }
+        }
+        // kernels launched earlier (on this editor's stream or a caller's) may still read the old tables
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(e->d_bright, bright.data(), bright.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_hsl, hsl.data(), hsl.size() * sizeof(ushort4), hipMemcpyHostToDevice));
+        const rpf_gpu_edit_parameters g0 = convert_params(e->state.masks[0].params);
+        e->dev.vign_strength = (-g0.vignette / 100.0f) * 2.0f;     // wgsl:167 (main mask only, :276)
+        e->dev.lens_strength = -0.5f * (g0.lens_distortion / 100.0f);  // wgsl:110 (main mask only, :273)
+        e->dev.num_masks = n;
+        e->dev.bright = e->d_bright;
+        e->dev.hsl = e->d_hsl;
+        e->dev.tabs = e->proc->d_tabs;
+        e->uploaded_params = e->state.params_version;
+    }
+    if (e->uploaded_masks != e->state.masks_version) {
+        const uint32_t planes = n - 1;
+        const size_t plane = npix_of(e);
+        if (planes > e->mask_capacity) {
+            if (e->d_masks) HIP_TRY(hipFree(e->d_masks));
+            e->d_masks = nullptr;
+            HIP_TRY(hipMalloc((void**)&e->d_masks, plane * planes));
+            e->mask_capacity = planes;
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        for (uint32_t m = 1; m < n; ++m)
+            HIP_TRY(hipMemcpy(e->d_masks + (size_t)(m - 1) * plane, e->state.masks[m].binary.data(), plane,
+                              hipMemcpyHostToDevice));
+        e->dev.mask_planes = planes ? e->d_masks : nullptr;
+        e->uploaded_masks = e->state.masks_version;
+    }
+    return ok();
+}
+
+static int need_device(const rpf_editor* e)
+{
+    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor");
+    if (!e->proc)
+        return fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: headless editor has no device (no CPU fallback exists)");
+    return ok();
+}
+
+static int ensure_image_buffer(rpf_editor* e)
+{
+    if (!e->d_image) HIP_TRY(hipMalloc((void**)&e->d_image, npix_of(e) * 4 * sizeof(float)));
+    return ok();
+}
+
+// linear RGBA of a bayer editor (demosaic-only pass), cached
+static int ensure_linear(rpf_editor* e)
+{
+    if (e->original_valid) return ok();
+    if (!e->d_original) HIP_TRY(hipMalloc((void**)&e->d_original, npix_of(e) * 4 * sizeof(float)));
+    HIP_TRY(launch_demosaic(cfg_of(e->proc), e->d_cfa, e->raw, e->geom, e->d_original, e->stream));
+    e->original_valid = true;
+    return ok();
+}
+
+extern "C" {
+
+const char* rpf_last_error(void) { return g_last_error.c_str(); }
+const char* rpf_version(void) { return "rawphotoforge_amd 0.1 (gfx950)"; }
+
+int rpf_device_count(int* count)
+{
+    if (!count) return fail(RPF_ERR_INVALID_ARGUMENT, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount", RPF_ERR_GPU_INITIALIZATION); }
+    *count = n;
+    return ok();
+}
+
+int rpf_device_name(int device, char* buf, size_t buf_len)
+{
+    if (!buf || buf_len == 0) return fail(RPF_ERR_INVALID_ARGUMENT, "null buffer");
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties", RPF_ERR_GPU_INITIALIZATION);
+    std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    strncpy(buf, s.c_str(), buf_len - 1);
+    buf[buf_len - 1] = 0;
+    return ok();
+}
+
+int rpf_processor_create(int device, rpf_processor** out)
+{
+    if (!out) return fail(RPF_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount", RPF_ERR_GPU_INITIALIZATION);
+    if (device < 0 || device >= n)  // gpu_image_processing.rs:48-51: adapters.nth(index) is None
+        return fail(RPF_ERR_GPU_INITIALIZATION, "GPU initialization error: no device with index " +
+                                                    std::to_string(device) + " (" + std::to_string(n) + " visible)");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties", RPF_ERR_GPU_INITIALIZATION);
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(RPF_ERR_GPU_INITIALIZATION, std::string("GPU initialization error: kernels are built for gfx950, "
+                                                            "device is ") + prop.gcnArchName);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice", RPF_ERR_GPU_INITIALIZATION);
+    std::unique_ptr<rpf_processor> p(new (std::nothrow) rpf_processor);
+    if (!p) return fail(RPF_ERR_GPU_INITIALIZATION, "out of host memory");
+    p->device = device;
+    p->num_cus = prop.multiProcessorCount;
+    std::unique_ptr<MathTables> tabs(new MathTables);
+    build_math_tables(*tabs);
+    e = hipMalloc((void**)&p->d_tabs, sizeof(MathTables));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(tables)", RPF_ERR_GPU_INITIALIZATION);
+    e = hipMemcpy(p->d_tabs, tabs.get(), sizeof(MathTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(p->d_tabs); return hip_fail(e, "hipMemcpy(tables)", RPF_ERR_GPU_INITIALIZATION); }
+    *out = p.release();
+    return ok();
+}
+
+void rpf_processor_destroy(rpf_processor* p)
+{
+    if (!p) return;
+    if (hipSetDevice(p->device) == hipSuccess && p->d_tabs) (void)hipFree(p->d_tabs);
+    delete p;
+}
+
+int rpf_processor_device(const rpf_processor* p, int* device)
+{
+    if (!p || !device) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *device = p->device;
+    return ok();
+}
+
+int rpf_processor_compute_units(const rpf_processor* p, int* cus)
+{
+    if (!p || !cus) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *cus = p->num_cus;
+    return ok();
+}
+
+int rpf_set_kernel_variant(rpf_processor* p, int variant)
+{
+    if (!p) return fail(RPF_ERR_INVALID_ARGUMENT, "null processor");
+    p->variant = variant;
+    return ok();
+}
+
+// ---- editors --------------------------------------------------------------------------------
+
+static int editor_device_init(rpf_editor* e, rpf_processor* p)
+{
+    e->proc = p;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    p->editors.fetch_add(1);
+    return ok();
+}
+
+void rpf_editor_destroy(rpf_editor* e)
+{
+    if (!e) return;
+    if (e->proc && hipSetDevice(e->proc->device) == hipSuccess) {
+        if (e->stream) (void)hipStreamSynchronize(e->stream);
+        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks};
+        for (void* b : bufs)
+            if (b) (void)hipFree(b);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+        e->proc->editors.fetch_sub(1);
+    }
+    delete e;
+}
+
+int rpf_editor_create_headless(uint32_t width, uint32_t height, rpf_editor** out)
+{
+    if (!out) return fail(RPF_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    rpf_editor* e = new (std::nothrow) rpf_editor(width, height);
+    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "out of host memory");
+    e->geom = TileGeom{width, height, 0, height};
+    *out = e;
+    return ok();
+}
+
+int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_editor** out)
+{
+    if (!p || !tile || !out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (tile->frame_width == 0 || tile->rows == 0 || (uint64_t)tile->y0 + tile->rows > tile->frame_height)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "tile outside its frame");
+    // masks and the state machine are tile-sized: rows x frame_width
+    std::unique_ptr<rpf_editor> e(new (std::nothrow) rpf_editor(tile->frame_width, tile->rows));
+    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "out of host memory");
+    e->geom = TileGeom{tile->frame_width, tile->frame_height, tile->y0, tile->rows};
+    int rc = editor_device_init(e.get(), p);
+    if (rc) { rpf_editor_destroy(e.release()); return rc; }
+    *out = e.release();
+    return ok();
+}
+
+int rpf_editor_create_from_rgb_f32(rpf_processor* p, const float* rgb, uint32_t width, uint32_t height,
+                                   rpf_editor** out)
+{
+    if (!p || !out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (!rgb || width == 0 || height == 0)  // errors.rs:9-13
+        return fail(RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: empty image");
+    rpf_tile t{width, height, 0, height};
+    rpf_editor* e = nullptr;
+    int rc = rpf_editor_create_for_tile(p, &t, &e);
+    if (rc) return rc;
+    auto cleanup = [&](int code) { rpf_editor_destroy(e); return code; };
+    const size_t npix = (size_t)width * height;
+    float* d_rgb = nullptr;
+    hipError_t he = hipMalloc((void**)&d_rgb, npix * 3 * sizeof(float));
+    if (he != hipSuccess) return cleanup(hip_fail(he, "hipMalloc(rgb)"));
+    he = hipMalloc((void**)&e->d_original, npix * 4 * sizeof(float));
+    if (he == hipSuccess) he = hipMemcpy(d_rgb, rgb, npix * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = launch_pad_rgb(d_rgb, npix, e->d_original, e->stream);  // image.rs:135-139
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_rgb);
+    if (he != hipSuccess) return cleanup(hip_fail(he, "upload"));
+    e->original_valid = true;
+    e->owns_image = true;
+    *out = e;
+    return ok();
+}
+
+int rpf_editor_create_from_bayer_u16(rpf_processor* p, const uint16_t* cfa, uint32_t width, uint32_t height,
+                                     const rpf_raw_params* raw, rpf_editor** out)
+{
+    if (!p || !out || !raw) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (!cfa || width < 3 || height < 3)
+        return fail(RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: a Bayer frame needs at least 3x3 samples");
+    for (int c = 0; c < 4; ++c)
+        if (!(raw->white > raw->black[c]))
+            return fail(RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: white level must exceed black level");
+    rpf_tile t{width, height, 0, height};
+    rpf_editor* e = nullptr;
+    int rc = rpf_editor_create_for_tile(p, &t, &e);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)width * sizeof(uint16_t);
+    hipError_t he = hipMalloc((void**)&e->d_cfa, row_bytes * (height + 4));
+    if (he == hipSuccess) he = hipMemset(e->d_cfa, 0, row_bytes * (height + 4));
+    if (he == hipSuccess)
+        he = hipMemcpy(reinterpret_cast<unsigned char*>(e->d_cfa) + 2 * row_bytes, cfa, row_bytes * height,
+                       hipMemcpyHostToDevice);
+    if (he != hipSuccess) { rpf_editor_destroy(e); return hip_fail(he, "upload CFA"); }
+    e->is_bayer = true;
+    e->raw = make_raw_params(*raw);
+    e->owns_image = true;
+    *out = e;
+    return ok();
+}
+
+int rpf_width(const rpf_editor* e, uint32_t* width)
+{
+    if (!e || !width) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *width = e->geom.width;
+    return ok();
+}
+int rpf_height(const rpf_editor* e, uint32_t* height)
+{
+    if (!e || !height) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *height = e->geom.rows;
+    return ok();
+}
+
+#define STATE_CALL(expr)                                   \
+    do {                                                   \
+        if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor"); \
+        Status _st = (expr);                               \
+        return _st ? ok() : fail(_st);                     \
+    } while (0)
+
+int rpf_set_whitebalance(rpf_editor* e, int32_t temperature, int32_t tint, const char* mask_name)
+{
+    STATE_CALL(e->state.set_whitebalance(temperature, tint, mask_name));
+}
+int rpf_set_vignette(rpf_editor* e, int32_t value) { STATE_CALL(e->state.set_vignette(value)); }
+int rpf_set_lens_distortion_correction(rpf_editor* e, int32_t value) { STATE_CALL(e->state.set_lens_distortion(value)); }
+int rpf_set_tone(rpf_editor* e, float exposure, int32_t contrast, int32_t shadow, int32_t highlight, int32_t black,
+                 int32_t white, const char* mask_name)
+{
+    STATE_CALL(e->state.set_tone(exposure, contrast, shadow, highlight, black, white, mask_name));
+}
+int rpf_set_brightness_tone_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs,
+                                  size_t n_x, const int32_t* ys, size_t n_y, const char* mask_name)
+{
+    STATE_CALL(e->state.set_curve(RPF_CURVE_BRIGHTNESS, curve, curve_len, xs, n_x, ys, n_y, mask_name));
+}
+int rpf_set_oklch_hue_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs, size_t n_x,
+                            const int32_t* ys, size_t n_y, const char* mask_name)
+{
+    STATE_CALL(e->state.set_curve(RPF_CURVE_HUE, curve, curve_len, xs, n_x, ys, n_y, mask_name));
+}
+int rpf_set_oklch_saturation_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs,
+                                   size_t n_x, const int32_t* ys, size_t n_y, const char* mask_name)
+{
+    STATE_CALL(e->state.set_curve(RPF_CURVE_SATURATION, curve, curve_len, xs, n_x, ys, n_y, mask_name));
+}
+int rpf_set_oklch_lightness_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs,
+                                  size_t n_x, const int32_t* ys, size_t n_y, const char* mask_name)
+{
+    STATE_CALL(e->state.set_curve(RPF_CURVE_LIGHTNESS, curve, curve_len, xs, n_x, ys, n_y, mask_name));
+}
+int rpf_add_mask(rpf_editor* e, const char* name, const float* mask) { STATE_CALL(e->state.add_mask(name, mask)); }
+int rpf_remove_mask(rpf_editor* e, const char* name) { STATE_CALL(e->state.remove_mask(name)); }
+
+int rpf_set_mask_range(rpf_editor* e, float mask_range)
+{
+    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor");
+    e->state.masks[0].params.mask_range = mask_range;
+    return ok();
+}
+
+int rpf_reset(rpf_editor* e)
+{
+    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor");
+    e->state.reset();
+    e->image_valid = false;  // lib.rs:228: image = original_image.clone()
+    return ok();
+}
+
+int rpf_num_masks(const rpf_editor* e, uint32_t* n)
+{
+    if (!e || !n) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *n = (uint32_t)e->state.masks.size();
+    return ok();
+}
+
+int rpf_editor_get_gpu_params(const rpf_editor* e, const char* mask_name, rpf_gpu_edit_parameters* out)
+{
+    if (!e || !out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    Status st;
+    const EditParameters* p = e->state.find(mask_name, st);
+    if (!p) return fail(st);
+    *out = convert_params(*p);
+    return ok();
+}
+
+int rpf_editor_get_curve(const rpf_editor* e, int which, const char* mask_name, int32_t* out65536)
+{
+    if (!e || !out65536 || which < 0 || which > 3) return fail(RPF_ERR_INVALID_ARGUMENT, "bad argument");
+    Status st;
+    const EditParameters* p = e->state.find(mask_name, st);
+    if (!p) return fail(st);
+    memcpy(out65536, p->curve[which].data(), sizeof(int32_t) * RPF_CURVE_RESOLUTION);
+    return ok();
+}
+
+int rpf_pchip_interpolate_i32(const int32_t* x_pts, size_t n_x, const int32_t* y_pts, size_t n_y,
+                              const int32_t* x_eval, size_t n_eval, int32_t* y_eval, int32_t* bad_index)
+{
+    if ((n_x && !x_pts) || (n_y && !y_pts) || (n_eval && (!x_eval || !y_eval)))
+        return fail(RPF_ERR_INVALID_ARGUMENT, "null array");
+    Status st = pchip_interpolate_i32(x_pts, n_x, y_pts, n_y, x_eval, n_eval, y_eval, bad_index);
+    return st ? ok() : fail(st);
+}
+
+// ---- apply / readback -----------------------------------------------------------------------
+
+int rpf_apply_adjustments(rpf_editor* e)
+{
+    int rc = need_device(e);
+    if (rc) return rc;
+    if (!e->owns_image) return fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: tile editor has no image; use rpf_dev_*");
+    HIP_TRY(hipSetDevice(e->proc->device));
+    if ((rc = sync_edit_state(e))) return rc;
+    if ((rc = ensure_image_buffer(e))) return rc;
+    const LaunchCfg cfg = cfg_of(e->proc);
+    if (e->is_bayer && e->dev.lens_strength == 0.0f) {
+        HIP_TRY(launch_develop(cfg, e->d_cfa, e->raw, e->geom, e->dev, e->d_image, OUT_RGBA_F32, e->stream));
+    } else {
+        if (e->is_bayer && (rc = ensure_linear(e))) return rc;  // resampling needs the demosaiced frame
+        HIP_TRY(launch_apply(cfg, e->d_original, e->geom, e->dev, e->d_image, OUT_RGBA_F32, e->stream));
+    }
+    e->image_valid = true;
+    return ok();  // asynchronous like queue.submit (gpu_image_processing.rs:391-399)
+}
+
+int rpf_editor_sync(rpf_editor* e)
+{
+    int rc = need_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->proc->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ok();
+}
+
+static int current_image(rpf_editor* e, const float** d_img)
+{
+    int rc = need_device(e);
+    if (rc) return rc;
+    if (!e->owns_image) return fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: tile editor has no image; use rpf_dev_*");
+    HIP_TRY(hipSetDevice(e->proc->device));
+    if (e->image_valid) {
+        *d_img = e->d_image;
+    } else {  // PhotoEditor.image starts as the original (lib.rs:113-114)
+        if (e->is_bayer && (rc = ensure_linear(e))) return rc;
+        *d_img = e->d_original;
+    }
+    return ok();
+}
+
+int rpf_get_rgba_f32(rpf_editor* e, float* out)
+{
+    if (!out) return fail(RPF_ERR_INVALID_ARGUMENT, "null out");
+    const float* img = nullptr;
+    int rc = current_image(e, &img);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out, img, npix_of(e) * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return ok();
+}
+
+static int readback_repacked(rpf_editor* e, void* out, int fmt, size_t bytes_per_px)
+{
+    if (!out) return fail(RPF_ERR_INVALID_ARGUMENT, "null out");
+    const float* img = nullptr;
+    int rc = current_image(e, &img);
+    if (rc) return rc;
+    const size_t bytes = npix_of(e) * bytes_per_px;
+    if (e->scratch_bytes < bytes) {
+        if (e->d_scratch) HIP_TRY(hipFree(e->d_scratch));
+        e->d_scratch = nullptr;
+        HIP_TRY(hipMalloc(&e->d_scratch, bytes));
+        e->scratch_bytes = bytes;
+    }
+    HIP_TRY(launch_repack(img, npix_of(e), e->d_scratch, fmt, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out, e->d_scratch, bytes, hipMemcpyDeviceToHost));
+    return ok();
+}
+
+int rpf_get_rgb_f32(rpf_editor* e, float* out) { return readback_repacked(e, out, OUT_RGB_F32, 3 * sizeof(float)); }
+int rpf_get_rgb_u8(rpf_editor* e, uint8_t* out) { return readback_repacked(e, out, OUT_RGB_U8, 3); }
+
+// ---- device-pointer layer -------------------------------------------------------------------
+
+int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_params* raw, const rpf_tile* tile,
+                     float* d_rgba_out, void* stream)
+{
+    if (!p || !d_cfa || !raw || !tile || !d_rgba_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    const TileGeom g{tile->frame_width, tile->frame_height, tile->y0, tile->rows};
+    HIP_TRY(launch_demosaic(cfg_of(p), d_cfa, make_raw_params(*raw), g, d_rgba_out, (hipStream_t)stream));
+    return ok();
+}
+
+int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* raw, void* d_out, int out_format,
+                    void* stream)
+{
+    int rc = need_device(e);
+    if (rc) return rc;
+    if (!d_cfa || !raw || !d_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(e->proc->device));
+    if ((rc = sync_edit_state(e))) return rc;
+    if (e->dev.lens_strength != 0.0f)
+        return fail(RPF_ERR_INVALID_ARGUMENT,
+                    "lens distortion resamples the whole frame: demosaic first, then rpf_dev_apply on the full frame");
+    HIP_TRY(launch_develop(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->dev, d_out, out_format,
+                           (hipStream_t)stream));
+    return ok();
+}
+
+int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_format, void* stream)
+{
+    int rc = need_device(e);
+    if (rc) return rc;
+    if (!d_rgba_in || !d_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(e->proc->device));
+    if ((rc = sync_edit_state(e))) return rc;
+    if (e->dev.lens_strength != 0.0f && (e->geom.y0 != 0 || e->geom.rows != e->geom.height))
+        return fail(RPF_ERR_INVALID_ARGUMENT, "lens distortion resamples the whole frame: the tile must be the frame");
+    HIP_TRY(launch_apply(cfg_of(e->proc), d_rgba_in, e->geom, e->dev, d_out, out_format, (hipStream_t)stream));
+    return ok();
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// rpf_chain.h — the per-pixel arithmetic of the hot path, shared by the gfx950
+// kernels (rpf_kernels.hip) and by a host build used ONLY by tests/ as a twin of
+// the device code (tests/twin/).  Every binary32 operation is written in the order
+// of rust/photo-editor/src/wgpu_shader.wgsl and must be compiled with
+// -ffp-contract=off; the transcendental builtins come from rpf_math.h.
+#pragma once
+#include "rpf_math.h"
+
+namespace rpf {
+
+#define RPF_MAX_MASKS 8
+#define RPF_CURVE_RESOLUTION 65536  // lib.rs:17
+
+enum MaskFlags : uint32_t {
+    MF_BLACK = 1u << 0,            // black != 0      wgsl:234
+    MF_WHITE = 1u << 1,            // white != 0      wgsl:241
+    MF_CONTRAST = 1u << 2,         // contrast != 0   wgsl:248
+    MF_BRIGHT_IDENTITY = 1u << 3,  // brightness_curve[i] == i for all i (after the fetch clamp)
+    MF_HUE_IDENTITY = 1u << 4,     // hue_curve[i] == i
+    MF_SAT_CONST = 1u << 5,        // saturation_curve constant -> sat_gain
+    MF_LIGHT_CONST = 1u << 6,      // lightness_curve constant -> light_gain
+};
+
+// One mask's uniform parameters: GpuEditParameters (gpu_image_processing.rs:18-32)
+// with the per-pixel-invariant sub-expressions of wgsl tone() evaluated once on the
+// host in the same binary32 arithmetic.
+struct MaskParams {
+    float r_gain, g_gain, b_gain;   // wgsl:285-288
+    float exposure_mul;             // pow(2.0, exposure), correctly rounded   wgsl:214
+    float shadow, highlight;        // wgsl:227, 231
+    float black, white;             // wgsl:234-245
+    float contrast_c;               // 1.0 + contrast                          wgsl:250
+    uint32_t flags;
+    float sat_gain, light_gain;     // f32(v) / 32767.5 when the curve is constant  wgsl:329-330
+};
+
+struct RawParamsDev {
+    float black[4], range[4], scale[4];  // per RGGB cell position (cx + 2 cy)
+    float cam[9];                        // row major camera -> linear sRGB
+    int xo, yo;                          // CFA phase
+};
+
+RPF_HD float clampf(float v, float lo, float hi)
+{
+    const float m = v > lo ? v : lo;  // WGSL clamp = min(max(e, low), high)
+    return m < hi ? m : hi;
+}
+
+// ---------------------------------------------------------------------------
+// RAW front half (this build's definition; see oracle/rpf_oracle.c orc_demosaic)
+// ---------------------------------------------------------------------------
+
+RPF_HD int reflect101(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+RPF_HD float cfa_normalise(uint32_t raw, int cell, const RawParamsDev& rp)
+{
+    const float n = clampf((float)raw - rp.black[cell], 0.0f, rp.range[cell]);
+    return n * rp.scale[cell];
+}
+
+RPF_HD float mhc_cross(float c, float s1, float e1, float v2, float h2)
+{
+    return ((4.0f * c + 2.0f * (s1 + e1)) - (v2 + h2)) * 0.125f;
+}
+RPF_HD float mhc_diag(float c, float d, float v2, float h2)
+{
+    return ((6.0f * c + 2.0f * d) - 1.5f * (v2 + h2)) * 0.125f;
+}
+RPF_HD float mhc_axis(float c, float along, float d, float same2, float other2)
+{
+    // horiz: along = e1, same2 = h2, other2 = v2;  vert: along = s1, same2 = v2, other2 = h2
+    return ((((5.0f * c + 4.0f * along) - d) - same2) + 0.5f * other2) * 0.125f;
+}
+
+// cx, cy: RGGB cell position of the site.  Inputs are the six neighbourhood sums.
+RPF_HD void mhc_site(int cx, int cy, float c, float s1, float e1, float d, float v2, float h2,
+                     float& R, float& G, float& B)
+{
+    if (cx == cy) {
+        const float cross = mhc_cross(c, s1, e1, v2, h2);
+        const float diag = mhc_diag(c, d, v2, h2);
+        G = cross;
+        if (cx == 0) { R = c; B = diag; } else { B = c; R = diag; }
+    } else {
+        const float horiz = mhc_axis(c, e1, d, h2, v2);
+        const float vert = mhc_axis(c, s1, d, v2, h2);
+        G = c;
+        if (cy == 0) { R = horiz; B = vert; } else { B = horiz; R = vert; }
+    }
+}
+
+RPF_HD void cam_to_linear(const float* m, float R, float G, float B, float& r, float& g, float& b)
+{
+    r = m[0] * R + m[1] * G + m[2] * B;
+    g = m[3] * R + m[4] * G + m[5] * B;
+    b = m[6] * R + m[7] * G + m[8] * B;
+}
+
+// ---------------------------------------------------------------------------
+// wgsl:166-178 vignette — returns the gain; x, y are GLOBAL pixel coordinates
+// ---------------------------------------------------------------------------
+RPF_HD float vignette_gain(float vign_strength, int x, int y, float w, float h)
+{
+    const float cx = ((float)x / w - 0.5f) * 1.5f;
+    const float cy = ((float)y / h - 0.5f) * 1.5f;
+    const float dist = __builtin_sqrtf(cx * cx + cy * cy);
+    const float falloff = pow_1p5(clampf((dist - 0.25f) / 0.75f, 0.0f, 1.0f));
+    return clampf(1.0f - (vign_strength * falloff), 0.0f, 4.0f);
+}
+
+// ---------------------------------------------------------------------------
+// wgsl:109-164 lens_distortion_sample, strength != 0 branch.
+// fetch(x, y, rgb[3]) reads one RGBA32F texel of the whole frame.
+// ---------------------------------------------------------------------------
+RPF_HD float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+template <class Fetch>
+RPF_HD void lens_sample(const Fetch& fetch, int w_u, int h_u, int x, int y, float strength, float& r, float& g,
+                        float& b)
+{
+    const float w = (float)w_u, h = (float)h_u;
+    const float uvx = (float)x / w, uvy = (float)y / h;
+    const float cux = uvx - 0.5f, cuy = uvy - 0.5f;
+    const float aspect = w / h;
+    const float kx = cux * aspect, ky = cuy * 1.0f;
+    const float r2 = kx * kx + ky * ky;
+    const float den = 1.0f + strength * r2;
+    const float dx = kx / den, dy = ky / den;
+    const float fx = (dx / aspect) + 0.5f, fy = (dy / 1.0f) + 0.5f;
+    if (fx < 0.0f || fy < 0.0f || fx > 1.0f || fy > 1.0f) {
+        r = g = b = 0.0f;
+        return;
+    }
+    const float px = fx * (w - 1.0f), py = fy * (h - 1.0f);
+    const float x0f = __builtin_floorf(px), y0f = __builtin_floorf(py);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = x0 + 1 < w_u - 1 ? x0 + 1 : w_u - 1;
+    const int y1 = y0 + 1 < h_u - 1 ? y0 + 1 : h_u - 1;
+    const float tx = px - x0f, ty = py - y0f;
+    float c00[3], c10[3], c01[3], c11[3];
+    fetch(x0, y0, c00);
+    fetch(x1, y0, c10);
+    fetch(x0, y1, c01);
+    fetch(x1, y1, c11);
+    float o[3];
+    for (int k = 0; k < 3; ++k) o[k] = mixf(mixf(c00[k], c10[k], tx), mixf(c01[k], c11[k], tx), ty);
+    r = o[0]; g = o[1]; b = o[2];
+}
+
+// ---------------------------------------------------------------------------
+// wgsl main :279-336 — everything after the input sample and the vignette.
+//
+//   Luts::brightness(m, idx)               -> u32 in [0, 65535]   (lut_fetch(0u, ..))
+//   Luts::hsl(m, idx, hue, sat_f, light_f) -> hue u32, gains = f32(v)/32767.5
+//   active: bit m set <=> masks_tex(xy, m) == 1.0 (bit 0, "main", is all ones: lib.rs:193-196)
+// ---------------------------------------------------------------------------
+#define RPF_F(x) ((float)(x))
+
+template <class Luts, class Tabs>
+RPF_HD void edit_chain(float r, float g, float b, uint32_t active, const MaskParams* mp, uint32_t num_masks,
+                       const Luts& luts, const Tabs& T, float& o0, float& o1, float& o2)
+{
+    const float inv65535 = (float)(1.0 / 65535.0);
+    for (uint32_t m = 0; m < num_masks; ++m) {
+        if (!((active >> m) & 1u)) continue;
+        const MaskParams& P = mp[m];
+        r = r * P.r_gain; g = g * P.g_gain; b = b * P.b_gain;
+        // tone(), wgsl:200-259
+        r *= P.exposure_mul; g *= P.exposure_mul; b *= P.exposure_mul;
+        const float luma = r * RPF_F(0.2126) + g * RPF_F(0.7152) + b * RPF_F(0.0722);
+        const float shadow_mask = clampf(1.0f - luma, 0.0f, 1.0f);
+        const float highlight_mask = clampf(luma, 0.0f, 1.0f);
+        const float shadow_gain = 1.0f + P.shadow * shadow_mask;
+        r *= shadow_gain; g *= shadow_gain; b *= shadow_gain;
+        const float highlight_gain = 1.0f + P.highlight * highlight_mask;
+        r *= highlight_gain; g *= highlight_gain; b *= highlight_gain;
+        if (P.flags & MF_BLACK) {
+            const float t1 = 1.0f - highlight_mask;
+            const float add = P.black * (t1 * t1);  // pow(1 - t, 2.0) correctly rounded
+            r += add; g += add; b += add;
+        }
+        if (P.flags & MF_WHITE) {
+            const float add = P.white * (highlight_mask * highlight_mask);
+            r += add; g += add; b += add;
+        }
+        if (P.flags & MF_CONTRAST) {
+            r = (r - 0.5f) * P.contrast_c + 0.5f;
+            g = (g - 0.5f) * P.contrast_c + 0.5f;
+            b = (b - 0.5f) * P.contrast_c + 0.5f;
+        }
+        r = clampf(r, 0.0f, 1.0f); g = clampf(g, 0.0f, 1.0f); b = clampf(b, 0.0f, 1.0f);
+        // brightness curve, wgsl:293-305
+        uint32_t ru = (uint32_t)(r * 65535.0f), gu = (uint32_t)(g * 65535.0f), bu = (uint32_t)(b * 65535.0f);
+        if (!(P.flags & MF_BRIGHT_IDENTITY)) {
+            ru = luts.brightness(m, ru); gu = luts.brightness(m, gu); bu = luts.brightness(m, bu);
+        }
+        r = div_u16_by(ru, 65535.0f, inv65535);
+        g = div_u16_by(gu, 65535.0f, inv65535);
+        b = div_u16_by(bu, 65535.0f, inv65535);
+    }
+
+    // linear_srgb_to_oklch, wgsl:64-75
+    const float l = RPF_F(0.4122214708) * r + RPF_F(0.5363325363) * g + RPF_F(0.0514459929) * b;
+    const float mm = RPF_F(0.2119034982) * r + RPF_F(0.6806995451) * g + RPF_F(0.1073969566) * b;
+    const float s = RPF_F(0.0883024619) * r + RPF_F(0.2817188376) * g + RPF_F(0.6299787005) * b;
+    const float lc = powc(l > 0.0f ? l : 0.0f, T.cbrt);
+    const float mc = powc(mm > 0.0f ? mm : 0.0f, T.cbrt);
+    const float sc = powc(s > 0.0f ? s : 0.0f, T.cbrt);
+    float L = RPF_F(0.2104542553) * lc + RPF_F(0.7936177850) * mc + RPF_F(-0.0040720468) * sc;
+    const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
+    const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;
+    float C = __builtin_sqrtf(A * A + Bq * Bq);
+    float h = atan2_cr(Bq, A) / RPF_K_TWO_PI_F;
+    if (h < 0.0f) h += 1.0f;
+
+    // per-mask OKLCH curves, wgsl:312-331
+    uint32_t hue_k = 0;
+    bool quantised = false;
+    for (uint32_t m = 0; m < num_masks; ++m) {
+        if (!((active >> m) & 1u)) continue;
+        const MaskParams& P = mp[m];
+        const uint32_t hu = (uint32_t)(h * 65535.0f);
+        uint32_t nh = hu;
+        float sat_gain = P.sat_gain, light_gain = P.light_gain;
+        if ((P.flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) !=
+            (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST))
+            luts.hsl(m, hu, P, nh, sat_gain, light_gain);
+        hue_k = nh;
+        quantised = true;
+        h = div_u16_by(nh, 65535.0f, inv65535);
+        C = C * sat_gain;
+        L = L * light_gain;
+    }
+
+    // oklch_to_linear_srgb, wgsl:77-84
+    float cs, sn;
+    if (quantised) {
+        sincos_hue(hue_k, T.sc, cs, sn);
+    } else {  // no active mask at this pixel: only reachable if "main" were not all ones
+        slow_sincosf((h * 2.0f) * RPF_K_PI_F, cs, sn);
+    }
+    const float oa = C * cs, ob = C * sn;
+    const float l_ = RPF_F(1.0) * L + RPF_F(0.3963377774) * oa + RPF_F(0.2158037573) * ob;
+    const float m_ = RPF_F(1.0) * L + RPF_F(-0.1055613458) * oa + RPF_F(-0.0638541728) * ob;
+    const float s_ = RPF_F(1.0) * L + RPF_F(-0.0894841775) * oa + RPF_F(-1.2914855480) * ob;
+    const float l3 = l_ * l_ * l_, m3 = m_ * m_ * m_, s3 = s_ * s_ * s_;
+    const float lr = RPF_F(4.0767416621) * l3 + RPF_F(-3.3077115913) * m3 + RPF_F(0.2309699292) * s3;
+    const float lg = RPF_F(-1.2684380046) * l3 + RPF_F(2.6097574011) * m3 + RPF_F(-0.3413193965) * s3;
+    const float lb = RPF_F(-0.0041960863) * l3 + RPF_F(-0.7034186147) * m3 + RPF_F(1.7076147010) * s3;
+
+    // linear_to_srgb + clamp, wgsl:95-103, 335-336
+    const float lin[3] = {lr, lg, lb};
+    float out[3];
+    for (int k = 0; k < 3; ++k) {
+        const float c = lin[k];
+        const float v = c <= RPF_F(0.0031308) ? c * RPF_F(12.92)
+                                              : RPF_F(1.055) * powc(c, T.gamma) - RPF_F(0.055);
+        out[k] = clampf(v, 0.0f, 1.0f);
+    }
+    o0 = out[0]; o1 = out[1]; o2 = out[2];
+}
+
+}  // namespace rpf

@@ -1,0 +1,367 @@
+// rpf_host.h — host-side operator state of the hot path (no HIP in here):
+// EditParameters / Mask bookkeeping, the setters' clamps and validation, PCHIP,
+// the EditParameters -> GpuEditParameters conversion and the packing of uniform
+// parameters and curves for the kernels.  Mirrors rust/photo-editor/src/lib.rs,
+// interpolation.rs and gpu_image_processing.rs:232-254.  Compile with
+// -ffp-contract=off: the f32 arithmetic here is part of the parity contract.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rpf.h"
+#include "rpf_chain.h"
+
+namespace rpf {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+struct Status {
+    int code = RPF_OK;
+    std::string msg;
+    static Status ok() { return {}; }
+    static Status err(int c, std::string m) { Status s; s.code = c; s.msg = std::move(m); return s; }
+    explicit operator bool() const { return code == RPF_OK; }
+};
+
+// ---------------------------------------------------------------------------
+// pchip_interpolate — interpolation.rs:11-123 (f32 arithmetic, op for op)
+// ---------------------------------------------------------------------------
+inline int32_t f32_as_i32(float v)  // Rust `as`: truncate, saturate, NaN -> 0
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+inline Status pchip_interpolate_i32(const int32_t* x_pts, size_t nx, const int32_t* y_pts, size_t ny,
+                                    const int32_t* x_eval, size_t n_eval, int32_t* y_eval, int32_t* bad_index)
+{
+    if (nx != ny)
+        return Status::err(RPF_ERR_INTERP_MISMATCHED_LENGTHS, "Input arrays must have the same length: x has " +
+                                                                  std::to_string(nx) + ", y has " + std::to_string(ny));
+    if (nx < 2)
+        return Status::err(RPF_ERR_INTERP_NOT_ENOUGH_POINTS,
+                           "At least two points are required for interpolation, but got " + std::to_string(nx));
+    const size_t n = nx;
+    std::vector<float> xp(n), yp(n), del(n - 1), h(n - 1), slopes(n, 0.0f);
+    for (size_t i = 0; i < n; ++i) { xp[i] = (float)x_pts[i]; yp[i] = (float)y_pts[i]; }
+    for (size_t i = 0; i + 1 < n; ++i) {
+        const float h_i = xp[i + 1] - xp[i];
+        if (h_i <= 0.0f) {
+            if (bad_index) *bad_index = (int32_t)i;
+            return Status::err(RPF_ERR_INTERP_NOT_STRICTLY_INCREASING,
+                               "x_pts must be strictly increasing, but found a non-increasing value at index " +
+                                   std::to_string(i));
+        }
+        h[i] = h_i;
+        del[i] = (yp[i + 1] - yp[i]) / h_i;
+    }
+    slopes[0] = del[0];
+    slopes[n - 1] = del[n - 2];
+    for (size_t i = 1; i + 1 < n; ++i) {
+        if (del[i - 1] * del[i] <= 0.0f) {
+            slopes[i] = 0.0f;
+        } else {
+            const float w1 = 2.0f * h[i] + h[i - 1];
+            const float w2 = h[i] + 2.0f * h[i - 1];
+            slopes[i] = (w1 + w2) / (w1 / del[i - 1] + w2 / del[i]);
+        }
+    }
+    for (size_t k = 0; k < n_eval; ++k) {
+        const float x = (float)x_eval[k];
+        float y;
+        if (x <= xp[0]) {
+            y = yp[0];
+        } else if (x >= xp[n - 1]) {
+            y = yp[n - 1];
+        } else {
+            size_t lo = 0, hi = n;  // last i with xp[i] <= x
+            while (lo < hi) {
+                const size_t mid = lo + (hi - lo) / 2;
+                if (xp[mid] <= x) lo = mid + 1; else hi = mid;
+            }
+            size_t i = lo - 1;
+            if (i > n - 2) i = n - 2;
+            const float h_val = h[i];
+            const float t = (x - xp[i]) / h_val;
+            const float t2 = t * t;
+            const float t3 = t2 * t;
+            const float h00 = 2.0f * t3 - 3.0f * t2 + 1.0f;
+            const float h10 = t3 - 2.0f * t2 + t;
+            const float h01 = -2.0f * t3 + 3.0f * t2;
+            const float h11 = t3 - t2;
+            y = h00 * yp[i] + h10 * h_val * slopes[i] + h01 * yp[i + 1] + h11 * h_val * slopes[i + 1];
+        }
+        y_eval[k] = f32_as_i32(y);
+    }
+    return Status::ok();
+}
+
+// ---------------------------------------------------------------------------
+// EditParameters / Mask — lib.rs:19-75
+// ---------------------------------------------------------------------------
+struct EditParameters {
+    float exposure = 0.0f;
+    int32_t contrast = 0, shadow = 0, highlight = 0, black = 0, white = 0;
+    int32_t wb_temperature = 0, wb_tint = 0;
+    int32_t vignette = 0;
+    int32_t lens_distortion = 0;
+    float mask_range = 0.0f;
+    std::vector<int32_t> curve[4];  // brightness, hue, saturation, lightness
+
+    EditParameters()
+    {
+        for (auto& c : curve) c.resize(RPF_CURVE_RESOLUTION);
+        for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) {  // lib.rs:58-61
+            curve[RPF_CURVE_BRIGHTNESS][i] = i;
+            curve[RPF_CURVE_HUE][i] = i;
+            curve[RPF_CURVE_SATURATION][i] = 32767;
+            curve[RPF_CURVE_LIGHTNESS][i] = 32767;
+        }
+    }
+};
+
+inline int32_t clamp_i32(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// gpu_image_processing.rs:235-247
+inline rpf_gpu_edit_parameters convert_params(const EditParameters& p)
+{
+    rpf_gpu_edit_parameters g;
+    g.r_gain = 1.0f + 0.5f * ((float)p.wb_temperature / 100.0f);
+    g.g_gain = 1.0f - 0.25f * ((float)p.wb_tint / 100.0f);
+    g.b_gain = 1.0f - 0.5f * ((float)p.wb_temperature / 100.0f);
+    g.vignette = (float)p.vignette;
+    g.lens_distortion = (float)p.lens_distortion;
+    g.exposure = p.exposure;
+    g.contrast = (float)p.contrast / 100.0f;
+    g.shadow = (float)p.shadow / 100.0f;
+    g.highlight = (float)p.highlight / 100.0f;
+    g.black = (float)p.black / 100.0f;
+    g.white = (float)p.white / 100.0f;
+    return g;
+}
+
+// pow(2.0, exposure) correctly rounded to binary32 (wgsl:214): long-double exp2 has 11
+// guard bits beyond binary64, far inside the margin needed for |exposure| <= 10.
+inline float exp2_cr(float e) { return (float)exp2l((long double)e); }
+
+inline uint32_t lut_clamp(int32_t v) { return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v)); }  // wgsl:188
+
+// Uniform block for one mask + what the kernels may skip.
+inline MaskParams make_mask_params(const EditParameters& p)
+{
+    const rpf_gpu_edit_parameters g = convert_params(p);
+    MaskParams m;
+    memset(&m, 0, sizeof(m));
+    m.r_gain = g.r_gain; m.g_gain = g.g_gain; m.b_gain = g.b_gain;
+    m.exposure_mul = exp2_cr(g.exposure);
+    m.shadow = g.shadow; m.highlight = g.highlight;
+    m.black = g.black; m.white = g.white;
+    m.contrast_c = 1.0f + g.contrast;
+    uint32_t f = 0;
+    if (g.black != 0.0f) f |= MF_BLACK;
+    if (g.white != 0.0f) f |= MF_WHITE;
+    if (g.contrast != 0.0f) f |= MF_CONTRAST;
+    bool ident_b = true, ident_h = true, const_s = true, const_l = true;
+    const uint32_t s0 = lut_clamp(p.curve[RPF_CURVE_SATURATION][0]);
+    const uint32_t l0 = lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][0]);
+    for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) {
+        ident_b = ident_b && lut_clamp(p.curve[RPF_CURVE_BRIGHTNESS][i]) == (uint32_t)i;
+        ident_h = ident_h && lut_clamp(p.curve[RPF_CURVE_HUE][i]) == (uint32_t)i;
+        const_s = const_s && lut_clamp(p.curve[RPF_CURVE_SATURATION][i]) == s0;
+        const_l = const_l && lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][i]) == l0;
+    }
+    if (ident_b) f |= MF_BRIGHT_IDENTITY;
+    if (ident_h) f |= MF_HUE_IDENTITY;
+    if (const_s) { f |= MF_SAT_CONST; m.sat_gain = (float)s0 / 32767.5f; }    // wgsl:329
+    if (const_l) { f |= MF_LIGHT_CONST; m.light_gain = (float)l0 / 32767.5f; }  // wgsl:330
+    m.flags = f;
+    return m;
+}
+
+inline void cfa_phase(uint32_t pattern, int& xo, int& yo)
+{
+    switch (pattern & 3u) {
+    default:
+    case RPF_CFA_RGGB: xo = 0; yo = 0; break;
+    case RPF_CFA_BGGR: xo = 1; yo = 1; break;
+    case RPF_CFA_GRBG: xo = 1; yo = 0; break;
+    case RPF_CFA_GBRG: xo = 0; yo = 1; break;
+    }
+}
+
+inline RawParamsDev make_raw_params(const rpf_raw_params& r)
+{
+    RawParamsDev d;
+    for (int c = 0; c < 4; ++c) {
+        d.black[c] = r.black[c];
+        d.range[c] = r.white - r.black[c];
+        d.scale[c] = r.wb[c] / d.range[c];
+    }
+    for (int i = 0; i < 9; ++i) d.cam[i] = r.cam2rgb[i];
+    cfa_phase(r.cfa_pattern, d.xo, d.yo);
+    return d;
+}
+
+// ---------------------------------------------------------------------------
+// EditState — the device-free half of PhotoEditor (lib.rs:77-84, 227-505)
+// ---------------------------------------------------------------------------
+struct MaskState {
+    std::string name;
+    EditParameters params;
+    std::vector<uint8_t> binary;  // empty for "main" (all ones, lib.rs:193-196)
+};
+
+struct EditState {
+    uint32_t width = 0, height = 0;
+    std::vector<MaskState> masks;
+    uint64_t params_version = 1;  // bumped by every setter; device copies are refreshed lazily
+    uint64_t masks_version = 1;
+
+    EditState(uint32_t w, uint32_t h) : width(w), height(h)
+    {
+        masks.emplace_back();
+        masks[0].name = "main";
+    }
+
+    EditParameters* find(const char* mask_name, Status& st)
+    {
+        const std::string name = mask_name ? mask_name : "main";
+        for (auto& m : masks)
+            if (m.name == name) return &m.params;
+        st = Status::err(RPF_ERR_MASK_NOT_FOUND, "Mask not found: The specified mask '" + name + "' does not exist.");
+        return nullptr;
+    }
+    const EditParameters* find(const char* mask_name, Status& st) const
+    {
+        return const_cast<EditState*>(this)->find(mask_name, st);
+    }
+
+    Status set_whitebalance(int32_t temperature, int32_t tint, const char* mask_name)  // lib.rs:255-265
+    {
+        Status st;
+        EditParameters* a = find(mask_name, st);
+        if (!a) return st;
+        a->wb_temperature = clamp_i32(temperature, -100, 100);
+        a->wb_tint = clamp_i32(tint, -100, 100);
+        ++params_version;
+        return st;
+    }
+    Status set_vignette(int32_t v)  // lib.rs:267-270
+    {
+        masks[0].params.vignette = clamp_i32(v, -100, 100);
+        ++params_version;
+        return Status::ok();
+    }
+    Status set_lens_distortion(int32_t v)  // lib.rs:272-275
+    {
+        masks[0].params.lens_distortion = clamp_i32(v, -100, 100);
+        ++params_version;
+        return Status::ok();
+    }
+    Status set_tone(float exposure, int32_t contrast, int32_t shadow, int32_t highlight, int32_t black,
+                    int32_t white, const char* mask_name)  // lib.rs:278-298
+    {
+        Status st;
+        EditParameters* a = find(mask_name, st);
+        if (!a) return st;
+        // f32::clamp(-10, 10): NaN stays NaN in Rust; keep that
+        a->exposure = exposure < -10.0f ? -10.0f : (exposure > 10.0f ? 10.0f : exposure);
+        a->contrast = clamp_i32(contrast, -100, 100);
+        a->shadow = clamp_i32(shadow, -100, 100);
+        a->highlight = clamp_i32(highlight, -100, 100);
+        a->black = clamp_i32(black, -100, 100);
+        a->white = clamp_i32(white, -100, 100);
+        ++params_version;
+        return st;
+    }
+
+    // lib.rs:300-479 (the four setters are copies of one another)
+    Status set_curve(int which, const int32_t* curve, size_t curve_len, const int32_t* xs, size_t n_x,
+                     const int32_t* ys, size_t n_y, const char* mask_name)
+    {
+        if (!curve && !xs)
+            return Status::err(RPF_ERR_INTERP_MISSING_CURVE_OR_CONTROL_POINTS,
+                               "Interpolation failed: You must provide either a full curve or control points.");
+        std::vector<int32_t> final_curve;
+        if (curve) {
+            if (curve_len != RPF_CURVE_RESOLUTION)
+                return Status::err(RPF_ERR_INTERP_INVALID_CURVE_LENGTH,
+                                   "Interpolation failed: The provided curve must have a length of 65536, but it was " +
+                                       std::to_string(curve_len));
+            final_curve.assign(curve, curve + curve_len);  // stored as given; clamped at fetch (wgsl:188)
+        } else {
+            if (!ys)
+                return Status::err(RPF_ERR_INTERP_MISSING_CONTROL_POINTS,
+                                   "Interpolation failed: Control points for x and y must be provided together.");
+            if (n_x != n_y)
+                return Status::err(RPF_ERR_INTERP_MISMATCHED_LENGTHS,
+                                   "Interpolation failed: Input arrays must have the same length: x has " +
+                                       std::to_string(n_x) + ", y has " + std::to_string(n_y));
+            if (n_x == 0)
+                return Status::err(RPF_ERR_INTERP_EMPTY_CONTROL_POINTS,
+                                   "Interpolation failed: Control point arrays cannot be empty.");
+            std::vector<int32_t> x_eval(RPF_CURVE_RESOLUTION);
+            for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) x_eval[i] = i;
+            final_curve.resize(RPF_CURVE_RESOLUTION);
+            Status st = pchip_interpolate_i32(xs, n_x, ys, n_y, x_eval.data(), x_eval.size(), final_curve.data(),
+                                              nullptr);
+            if (!st) { st.msg = "Interpolation failed: " + st.msg; return st; }
+            for (auto& v : final_curve) v = clamp_i32(v, 0, RPF_CURVE_RESOLUTION - 1);
+        }
+        Status st;
+        EditParameters* a = find(mask_name, st);  // looked up last, as in lib.rs:341
+        if (!a) return st;
+        a->curve[which] = std::move(final_curve);
+        ++params_version;
+        return st;
+    }
+
+    // lib.rs:481-499
+    Status add_mask(const char* name, const float* mask)
+    {
+        if (!name || !mask) return Status::err(RPF_ERR_INVALID_ARGUMENT, "add_mask: null argument");
+        if (masks.size() >= RPF_MAX_MASKS)
+            return Status::err(RPF_ERR_TOO_MANY_MASKS, "add_mask: at most " + std::to_string(RPF_MAX_MASKS) +
+                                                           " masks (including \"main\") per editor");
+        const float mask_range = masks[0].params.mask_range;
+        MaskState m;
+        m.name = name;
+        const size_t n = (size_t)width * height;
+        m.binary.resize(n);
+        for (size_t i = 0; i < n; ++i) m.binary[i] = mask[i] >= mask_range ? 1 : 0;
+        masks.push_back(std::move(m));
+        ++masks_version;
+        ++params_version;
+        return Status::ok();
+    }
+    Status remove_mask(const char* name)  // lib.rs:501-505
+    {
+        if (!name) return Status::err(RPF_ERR_INVALID_ARGUMENT, "remove_mask: null name");
+        const std::string n = name;
+        if (n != "main") {
+            for (size_t i = masks.size(); i-- > 0;)
+                if (masks[i].name == n) masks.erase(masks.begin() + (long)i);
+            ++masks_version;
+            ++params_version;
+        }
+        return Status::ok();
+    }
+    void reset()  // lib.rs:227-235 (the image half is the Editor's)
+    {
+        for (size_t i = masks.size(); i-- > 0;)
+            if (masks[i].name != "main") masks.erase(masks.begin() + (long)i);
+        for (auto& m : masks)
+            if (m.name == "main") { m.params = EditParameters(); break; }
+        ++masks_version;
+        ++params_version;
+    }
+};
+
+}  // namespace rpf

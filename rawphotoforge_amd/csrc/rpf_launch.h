@@ -1,0 +1,46 @@
+// rpf_launch.h — host-callable launchers of the gfx950 kernels (rpf_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "rpf_chain.h"
+
+namespace rpf {
+
+// Edit state as the kernels see it (all device pointers owned by the caller).
+struct DeviceEdit {
+    MaskParams mp[RPF_MAX_MASKS];
+    uint32_t num_masks;
+    const uint8_t* mask_planes;  // (num_masks - 1) planes of rows*width u8 (user masks), or null
+    const uint16_t* bright;      // num_masks x 65536 u16, clamped (wgsl:188)
+    const ushort4* hsl;          // num_masks x 65536 {hue, sat, light, 0}
+    const MathTables* tabs;
+    float vign_strength;         // (-vignette / 100) * 2, 0 = off       wgsl:167
+    float lens_strength;         // -0.5 * (lens_distortion / 100), 0 = off   wgsl:110
+};
+
+struct TileGeom {
+    uint32_t width, height;  // full frame
+    uint32_t y0, rows;       // this tile
+};
+
+enum OutFormat { OUT_RGBA_F32 = 0, OUT_RGB_F32 = 1, OUT_RGB_U8 = 2 };
+
+struct LaunchCfg {
+    int num_cus;
+    int variant;  // 0 default; see rpf_kernels.hip
+};
+
+// d_cfa: (rows + 4) x width u16, row r = frame row y0 - 2 + r
+hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
+                           float* d_rgba, hipStream_t s);
+hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
+                          const DeviceEdit& ed, void* d_out, int out_format, hipStream_t s);
+// d_in: rows x width RGBA32F (whole frame when lens_strength != 0)
+hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom& g, const DeviceEdit& ed, void* d_out,
+                        int out_format, hipStream_t s);
+// RGBA32F -> RGB f32 / RGB u8 repack (image.rs:202-277, 375-383)
+hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_format, hipStream_t s);
+// interleaved RGB f32 -> RGBA32F, alpha = 1 (image.rs:135-139)
+hipError_t launch_pad_rgb(const float* d_rgb, size_t npix, float* d_rgba, hipStream_t s);
+
+}  // namespace rpf

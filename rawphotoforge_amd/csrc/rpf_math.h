@@ -1,0 +1,187 @@
+// rpf_math.h — correctly rounded binary32 pow / atan2 / sincos for the edit chain,
+// written with IEEE-754 operations only (binary64 fma/mul/add, binary32 div), so a
+// host build of this header computes bit-for-bit what the gfx950 kernels compute.
+//
+// Why: WGSL leaves pow/atan2/sin/cos accuracy to the backend
+// (rust/photo-editor/src/wgpu_shader.wgsl:67,72,79,98); the parity oracle
+// (oracle/rpf_oracle.c) fixes them as CORRECTLY ROUNDED.  Hardware v_log/v_exp/
+// v_sin are 1-ulp-class approximations, and 1 ulp before a `u32(x * 65535)` LUT
+// index (wgsl:293-295, 320-322) or before M1_INV (wgsl:46-50) becomes many ulp
+// after it — so the kernels evaluate each transcendental in binary64 to < 2^-49
+// relative and round once.  The two pow domains that matter are small enough to
+// be checked exhaustively against the oracle (tests/test_math_exhaustive.py).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RPF_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define RPF_HD inline
+#endif
+
+namespace rpf {
+
+// ---------------------------------------------------------------------------
+// Tables (built once on the host by build_math_tables, staged in LDS by kernels)
+// ---------------------------------------------------------------------------
+
+// x^c = 2^(e c) * r_j^(-c) * (1 + t)^c,  x = 2^e m,  t = m r_j - 1 (exact in binary64)
+struct PowTable {
+    double E[64];        // E[e + 32] = 2^(e c),                 e in [-32, 31]
+    double TR[128][2];   // TR[j] = { r_j^(-c), r_j },          j = top 7 mantissa bits
+    double C[5];         // binomial(c, k), k = 1..5
+    float c;             // the binary32 exponent itself (slow path)
+    float pad;
+};
+
+// cos/sin of k * K_HUE_STEP split as k = 256 k1 + k0
+struct SinCosTable {
+    double hi[256][2];   // { cos, sin }(256 k1 * step)
+    double lo[256][2];   // { cos, sin }(k0 * step)
+};
+
+struct MathTables {
+    PowTable cbrt;       // c = f32(1/3)    wgsl:67
+    PowTable gamma;      // c = f32(1/2.4)  wgsl:98
+    SinCosTable sc;
+};
+
+// wgsl:78 `c.z * 2.0 * 3.14159265359`, wgsl:72 `2.0 * 3.14159265359`
+#define RPF_K_PI_F ((float)3.14159265359)
+#define RPF_K_TWO_PI_F ((float)(2.0 * 3.14159265359))
+
+// 2 * f32(3.14159265359) / 65535 as binary64 (tools/gen_math_consts.py)
+#define RPF_K_HUE_STEP 0x1.9221482148215p-14
+
+RPF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
+RPF_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+RPF_HD uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+RPF_HD float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// Out-of-domain fallbacks (never reached by the edit chain's value ranges): kept out
+// of line so the hot loop stays small in the instruction cache.
+#if defined(__HIPCC__)
+#define RPF_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define RPF_NOINLINE __attribute__((noinline))
+#endif
+RPF_NOINLINE static float slow_powf(float x, float y) { return (float)::pow((double)x, (double)y); }
+RPF_NOINLINE static float slow_atan2f(float y, float x) { return (float)::atan2((double)y, (double)x); }
+RPF_NOINLINE static void slow_sincosf(float a, float& cs, float& sn)
+{
+    cs = (float)::cos((double)a);
+    sn = (float)::sin((double)a);
+}
+
+// f32(k) / d for integer k in [0, 65535] and d in {65535, 32767.5}: q = k*r, one
+// fma residual, one fma correction.  Equal to the IEEE quotient for every k
+// (checked exhaustively in tests/test_math_exhaustive.py).  wgsl:303-305, 328-330.
+RPF_HD float div_u16_by(uint32_t k, float d, float rd)
+{
+    float kf = (float)k;
+    float q0 = kf * rd;
+    float e = __builtin_fmaf(-q0, d, kf);
+    return __builtin_fmaf(e, rd, q0);
+}
+
+// Correctly rounded x^c for x >= 0 (c fixed by the table).  Exhaustively equal
+// to the oracle's cr_powf on [2^-21, 2) for cbrt and [2^-9, 2^3) for gamma.
+template <class TabT>
+RPF_HD float powc(float x, const TabT& T)
+{
+    if (!(x > 0.0f)) return 0.0f;
+    const double xd = (double)x;
+    const uint64_t u = d2u(xd);
+    const uint32_t hi = (uint32_t)(u >> 32);
+    const int e = (int)((hi >> 20) & 0x7ffu) - 1023;
+    const uint32_t j = (hi >> 13) & 127u;
+    if ((uint32_t)(e + 32) >= 64u) return slow_powf(x, T.c);
+    const double m = u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    const double r = T.TR[j][1];
+    const double tj = T.TR[j][0];
+    const double t = __builtin_fma(m, r, -1.0);
+    double p = __builtin_fma(t, T.C[4], T.C[3]);
+    p = __builtin_fma(t, p, T.C[2]);
+    p = __builtin_fma(t, p, T.C[1]);
+    p = __builtin_fma(t, p, T.C[0]);
+    p = __builtin_fma(t, p, 1.0);
+    const double y = (T.E[e + 32] * tj) * p;
+    return (float)y;
+}
+
+// atan(q) = q + q^3 P(q^2), |q| <= tan(pi/8); rel. error 2^-52.7 (tools/gen_math_consts.py)
+RPF_HD double atan_small(double q)
+{
+    const double s = q * q;
+    double p = 0x1.74a2d785d5a9fp-6;
+    p = __builtin_fma(p, s, -0x1.6f3c3017cb4e7p-5);
+    p = __builtin_fma(p, s, 0x1.d5e885b7ee229p-5);
+    p = __builtin_fma(p, s, -0x1.105e007ccd67cp-4);
+    p = __builtin_fma(p, s, 0x1.3b0688e46275ap-4);
+    p = __builtin_fma(p, s, -0x1.745c7f2dc5c2dp-4);
+    p = __builtin_fma(p, s, 0x1.c71c6dcf1e479p-4);
+    p = __builtin_fma(p, s, -0x1.2492491dcf6e7p-3);
+    p = __builtin_fma(p, s, 0x1.9999999990a20p-3);
+    p = __builtin_fma(p, s, -0x1.5555555555546p-2);
+    return __builtin_fma(q * s, p, q);
+}
+
+// atan2(y, x) rounded to binary32 from a binary64 value with rel. error < 2^-49.
+RPF_HD float atan2_cr(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = ax > ay ? ax : ay;
+    const float mn = ax > ay ? ay : ax;
+    double r;
+    if (mx == 0.0f) {
+        r = 0.0;
+    } else if (!(mx < 1e37f) || mx < 1e-30f) {
+        return slow_atan2f(y, x);
+    } else {
+        const double dmx = (double)mx, dmn = (double)mn;
+        // theta in [0, pi/8]: q = mn/mx;  theta in (pi/8, pi/4]: pi/4 + atan((mn-mx)/(mn+mx))
+        const bool upper = mn > 0.41421356f * mx;
+        const double num = upper ? dmn - dmx : dmn;
+        const double den = upper ? dmn + dmx : dmx;
+        const float rc = 1.0f / (float)den;             // IEEE binary32 division
+        const double q0 = num * (double)rc;
+        const double res = __builtin_fma(-q0, den, num);
+        const double q = __builtin_fma(res, (double)rc, q0);  // rel. error ~2^-47 of a 2^-24 term
+        r = atan_small(q);
+        if (upper) r += 0x1.921fb54442d18p-1;          // pi/4
+        if (ay > ax) r = 0x1.921fb54442d18p+0 - r;      // pi/2 - r
+    }
+    if ((f2bits(x) >> 31) != 0u) r = 0x1.921fb54442d18p+1 - r;  // x < 0 or x == -0: pi - r
+    const float rf = (float)r;
+    return bits2f(f2bits(rf) | (f2bits(y) & 0x80000000u));      // copysign(rf, y)
+}
+
+// cos(a), sin(a) for a = f32(f32(k)/65535) * 2 * f32(pi), k in [0, 65535] — the
+// only arguments oklch_to_linear_srgb can see after the hue LUT (wgsl:324-328, 78-79).
+// Equal to the oracle's cr_cosf/cr_sinf for every k (tests/test_math_exhaustive.py).
+template <class TabT>
+RPF_HD void sincos_hue(uint32_t k, const TabT& S, float& cs, float& sn)
+{
+    const float h = div_u16_by(k, 65535.0f, (float)(1.0 / 65535.0));
+    const float a = (h * 2.0f) * RPF_K_PI_F;
+    const double delta = __builtin_fma(-(double)k, RPF_K_HUE_STEP, (double)a);  // |delta| < 2^-20
+    const double c1 = S.hi[k >> 8][0], s1 = S.hi[k >> 8][1];
+    const double c0 = S.lo[k & 255u][0], s0 = S.lo[k & 255u][1];
+    const double ce = __builtin_fma(c1, c0, -(s1 * s0));
+    const double se = __builtin_fma(s1, c0, c1 * s0);
+    const double q = __builtin_fma(-0.5 * delta, delta, 1.0);   // cos(delta) to 2^-80
+    cs = (float)__builtin_fma(-se, delta, ce * q);
+    sn = (float)__builtin_fma(ce, delta, se * q);
+}
+
+// pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171):
+// x*sqrt(x) in binary64 is within 2^-52 of the true value.
+RPF_HD float pow_1p5(float x)
+{
+    const double xd = (double)x;
+    return (float)(xd * __builtin_sqrt(xd));
+}
+
+}  // namespace rpf

@@ -1,0 +1,78 @@
+// rpf_twin.cpp — HOST build of the device arithmetic (rpf_math.h / rpf_chain.h).
+// TEST INFRASTRUCTURE ONLY: lets the CPU test-suite check, without a GPU, that the
+// IEEE-only transcendental code the kernels run agrees with the oracle (exhaustively
+// on the pow / sincos domains).  Never loaded by rawphotoforge_amd.
+#include "../../rawphotoforge_amd/csrc/rpf_chain.h"
+
+#include <stdint.h>
+#include <string.h>
+
+namespace rpf { void build_math_tables(MathTables& T); }
+
+static rpf::MathTables g_tab;
+static bool g_ready = false;
+static const rpf::MathTables& tabs()
+{
+    if (!g_ready) { rpf::build_math_tables(g_tab); g_ready = true; }
+    return g_tab;
+}
+
+struct HostLuts {
+    const int32_t* bright; const int32_t* hue; const int32_t* sat; const int32_t* light;
+    static uint32_t fetch(const int32_t* l, uint32_t m, uint32_t i)
+    {
+        int32_t v = l[(size_t)m * RPF_CURVE_RESOLUTION + i];
+        return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+    }
+    uint32_t brightness(uint32_t m, uint32_t i) const { return fetch(bright, m, i); }
+    void hsl(uint32_t m, uint32_t i, const rpf::MaskParams&, uint32_t& nh, float& sg, float& lg) const
+    {
+        nh = fetch(hue, m, i);
+        sg = rpf::div_u16_by(fetch(sat, m, i), 32767.5f, (float)(1.0 / 32767.5));
+        lg = rpf::div_u16_by(fetch(light, m, i), 32767.5f, (float)(1.0 / 32767.5));
+    }
+};
+
+extern "C" {
+
+float twin_pow_cbrt(float x) { return rpf::powc(x, tabs().cbrt); }
+float twin_pow_gamma(float x) { return rpf::powc(x, tabs().gamma); }
+float twin_atan2(float y, float x) { return rpf::atan2_cr(y, x); }
+void twin_sincos_hue(uint32_t k, float* cs, float* sn) { rpf::sincos_hue(k, tabs().sc, *cs, *sn); }
+float twin_pow_1p5(float x) { return rpf::pow_1p5(x); }
+float twin_div_u16(uint32_t k, float d) { return rpf::div_u16_by(k, d, 1.0f / d); }
+float twin_hue_angle(uint32_t k)
+{
+    const float h = rpf::div_u16_by(k, 65535.0f, (float)(1.0 / 65535.0));
+    return (h * 2.0f) * RPF_K_PI_F;
+}
+
+// range sweeps: count mismatches of twin f(x) against ref[] over consecutive bit patterns
+void twin_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
+{
+    const rpf::MathTables& T = tabs();
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) {
+        float x = rpf::bits2f(bits_lo + (uint32_t)i);
+        out[i] = which == 0 ? rpf::powc(x, T.cbrt) : rpf::powc(x, T.gamma);
+    }
+}
+
+// whole edit chain on npix pixels (rgb in, rgba out), masks all-ones
+void twin_edit_chain(const float* rgb, size_t npix, const rpf::MaskParams* mp, uint32_t num_masks,
+                     const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
+                     float* rgba_out)
+{
+    HostLuts L{bright, hue, sat, light};
+    const rpf::MathTables& T = tabs();
+    const uint32_t active = num_masks >= 32 ? 0xffffffffu : ((1u << num_masks) - 1u);
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)npix; ++i) {
+        float o0, o1, o2;
+        rpf::edit_chain(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], active, mp, num_masks, L, T, o0, o1, o2);
+        rgba_out[i * 4] = o0; rgba_out[i * 4 + 1] = o1; rgba_out[i * 4 + 2] = o2; rgba_out[i * 4 + 3] = 1.0f;
+    }
+}
+
+size_t twin_sizeof_mask_params(void) { return sizeof(rpf::MaskParams); }
+}

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Derive the polynomial constants hard-coded in rawphotoforge_amd/csrc/rpf_math.h.
+
+Build-time tool (needs mpmath, present in the build container only).  Prints C
+hex-float literals; the header carries the printed values so nothing here runs
+at build or run time.
+
+  atan:  atan(q) = q + q^3 * P(q^2) for |q| <= tan(pi/8) (+ margin), P of degree 9
+"""
+import mpmath as mp
+
+mp.mp.prec = 200
+
+
+def hexd(x):
+    return float(x).hex()
+
+
+def atan_poly(deg=9, qmax=mp.mpf("0.4143")):
+    smax = qmax * qmax
+
+    def g(s):
+        s = mp.mpf(s)
+        if s < mp.mpf(2) ** -60:
+            return -mp.mpf(1) / 3 + s / 5
+        q = mp.sqrt(s)
+        return (mp.atan(q) - q) / (q * s)
+
+    coeffs, err = mp.chebyfit(g, [0, smax], deg + 1, error=True)
+    coeffs = [float(c) for c in coeffs[::-1]]  # ascending powers, rounded to binary64
+    # true error of the ROUNDED polynomial, relative to atan(q), sampled densely
+    worst = mp.mpf(0)
+    for i in range(1, 4001):
+        q = qmax * i / 4000
+        s = q * q
+        p = mp.mpf(0)
+        for c in reversed(coeffs):
+            p = p * s + mp.mpf(c)
+        approx = q + q * s * p
+        worst = max(worst, abs(approx / mp.atan(q) - 1))
+    return coeffs, err, worst
+
+
+if __name__ == "__main__":
+    for deg in (7, 8, 9):
+        c, err, worst = atan_poly(deg)
+        print(f"// atan P degree {deg}: chebyfit err {mp.nstr(err, 5)}, rel err of rounded poly {mp.nstr(worst, 5)}"
+              f" = 2^{mp.nstr(mp.log(worst, 2), 5)}")
+        if deg in (8, 9):
+            print("static const double ATAN_P[] = {")
+            for v in c:
+                print(f"    {hexd(v)},")
+            print("};")
+    print("// pi/4, pi/2, pi as binary64")
+    for name, v in (("PI_4", mp.pi / 4), ("PI_2", mp.pi / 2), ("PI", mp.pi)):
+        print(f"static const double K_{name} = {hexd(v)};")
+    pif = float(mp.mpf(3.14159265359))  # wgsl:78 literal as binary64 ...
+    import struct
+    pif32 = struct.unpack("f", struct.pack("f", pif))[0]  # ... converted to binary32
+    print(f"// hue step 2*f32(3.14159265359)/65535 as binary64 (f32 pi = {pif32!r})")
+    print(f"static const double K_HUE_STEP = {hexd(mp.mpf(2) * mp.mpf(pif32) / 65535)};")
