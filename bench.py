@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py — megapixels/s of the full RAW -> sRGB chain on a 6000x4000 Bayer frame (BASELINE.json).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the fused kernel (demosaic + black level/WB + camera matrix + the whole of
+wgsl main: tone, brightness curve, OKLCH curves, gamma) over one synthetic frame band that is already
+resident in HBM.  N = 1: BASELINE configs[2], the 6000x4000 frame.  N > 1: weak scaling — a
+6000 x (4000 N) frame cut into N row bands, one per rank; every step each rank first exchanges its
+2-row Bayer halos with its neighbours (RCCL send/recv), then develops its band.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, from HIP-event
+kernel times on the launch stream) and `cpu_baseline` (the oracle on the host cores, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 6000, 4000
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_PX = {"develop": 18, "demosaic": 18, "apply": 32}   # u16 in + RGBA32F out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply"])
+    ap.add_argument("--params", default="D", choices=["D", "S", "G"])
+    ap.add_argument("--data", default="U", choices=["U", "N"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=600)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import rawphotoforge_amd as R
+    from rawphotoforge_amd import tiles
+    from rawphotoforge_amd import synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    gpu = R.GpuProcessor(local)
+    gpu.set_kernel_variant(args.variant)
+    frame_h = H * world
+    y0, rows = rank * H, H
+    praw = R.RawParams(**syn.RAW)
+    spec = syn.PARAM_SETS[args.params]
+    gen = syn.bayer_uniform if args.data == "U" else syn.bayer_natural
+    cfa = gen(rows, W, seed=20260630 + rank)          # this rank's band (rank 0 at N=1: THE frame)
+    band = tiles.make_band_buffer(cfa, device="cuda")   # (rows + 4, W) with halo rows
+    ed = R.PhotoEditor.for_tile(gpu, W, frame_h, y0, rows)
+    syn.configure(ed, spec)
+    out = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda")
+    lin = None
+    if args.workload == "apply":
+        lin = torch.empty_like(out)
+        R.dev_demosaic(gpu, band.data_ptr(), praw, W, frame_h, y0, rows, lin.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        tiles.exchange_halos(band, rank, world)          # no-op at N = 1
+        if i is not None:
+            ev[i][0].record()
+        if args.workload == "develop":
+            ed.dev_develop(band.data_ptr(), praw, out.data_ptr(), R.OUT_RGBA_F32, stream)
+        elif args.workload == "demosaic":
+            R.dev_demosaic(gpu, band.data_ptr(), praw, W, frame_h, y0, rows, out.data_ptr(), stream)
+        else:
+            ed.dev_apply(lin.data_ptr(), out.data_ptr(), R.OUT_RGBA_F32, stream)
+        if i is not None:
+            ev[i][1].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    mp_per_step = world * rows * W / 1e6
+    value = mp_per_step * args.steps / dt
+    bpp = BYTES_PER_PX[args.workload]
+    achieved = bpp * rows * W / (kern_avg_ms * 1e-3) / 1e9   # GB/s, algorithmic bytes of ONE launch
+
+    result = {
+        "metric": "megapixels/sec full RAW->sRGB chain, 6000x4000 Bayer; % HBM roofline",
+        "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": (f"{W}x{H} RGGB u16 -> RGBA32F per GPU, fused {args.workload} "
+                         f"(demosaic+WB+camera matrix+tone+curves+OKLCH+gamma), edit set {args.params}, "
+                         f"data ({args.data}), frame {W}x{frame_h} in {world} row band(s)"
+                         + (", 2-row halo exchange per step" if world > 1 else "")),
+            "variant": args.variant, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
+            "kernel_ms_min": round(kern_ms[0], 4),
+        },
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel_ms_avg": round(kern_avg_ms, 4), "bytes_per_px": bpp},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle as O   # the checker, timed as the reported CPU baseline (never on the GPU path)
+        from tests import util
+        raw, p = util.raw_params(), util.oracle_params(spec)
+        y_lo = (H - args.cpu_rows) // 2 & ~1
+        O.develop(cfa, raw, [p], y0=y_lo, rows=8)        # warm the library / thread pool
+        t1 = time.perf_counter()
+        O.develop(cfa, raw, [p], y0=y_lo, rows=args.cpu_rows)
+        ct = time.perf_counter() - t1
+        result["cpu_baseline"] = {
+            "value": round(args.cpu_rows * W / 1e6 / ct, 3), "unit": "MP/s", "cores": O.max_threads(), "kind": "port",
+            "sample": (f"oracle/rpf_oracle.c (C restatement, OpenMP) on rows [{y_lo},{y_lo + args.cpu_rows}) of the same "
+                       f"{W}x{H} frame = {args.cpu_rows * W / 1e6:.1f} MP, {ct:.1f} s"),
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Row-tile sharding of one frame across the GPUs of a node.
+
+The edit chain is pointwise and the demosaic is a 5x5 stencil, so a frame cut into contiguous row
+bands needs exactly one exchange step: each rank sends its first/last two Bayer rows to the rank
+above/below (2 x W x 2 B per direction) and receives theirs into the two halo rows that bracket its
+band buffer.  Neighbour-only send/recv over RCCL (torch.distributed, backend "nccl" on ROCm) — no
+all-reduce/all-gather exists on this path.  torch is plumbing here (device memory + the process
+group); the kernels are launched through the C ABI on raw device pointers.
+
+Band buffer layout (matches include/rpf.h rpf_dev_develop): (rows + 4) x W u16, row r holds frame
+row y0 - 2 + r; rows 0..1 and rows+2..rows+3 are halo.  Halo rows outside the frame are never read.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+HALO = 2
+
+
+def split_rows(height: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous bands [(y0, rows)] with even boundaries (so every band starts on the CFA phase of
+    row 0) and sizes differing by at most 2 rows."""
+    if world < 1 or height < 2 * world:
+        raise ValueError("need at least two rows per band")
+    cuts = [((height * r // world) // 2) * 2 for r in range(world)] + [height]
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
+def exchange_halos(band, rank: int, world: int, group=None) -> None:
+    """Fill `band`'s halo rows from the neighbouring ranks' edge rows.
+
+    band: torch tensor (rows + 4, W), any 2-byte dtype, contiguous, on the rank's device (or CPU for
+    gloo).  One batch of point-to-point ops; returns when the halos are usable on the current stream.
+    """
+    import torch.distributed as dist
+
+    if world == 1:
+        return
+    rows = band.shape[0] - 2 * HALO
+    if rows < HALO:
+        raise ValueError("a band must have at least 2 rows to feed its neighbours' halos")
+    ops = []
+    if rank > 0:  # neighbour above: my first two rows are its bottom halo
+        ops.append(dist.P2POp(dist.isend, band[HALO:2 * HALO], rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, band[0:HALO], rank - 1, group))
+    if rank < world - 1:  # neighbour below
+        ops.append(dist.P2POp(dist.isend, band[rows:rows + HALO], rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, band[rows + HALO:rows + 2 * HALO], rank + 1, group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def make_band_buffer(cfa_band, device=None):
+    """(rows, W) uint16 numpy -> (rows + 4, W) int16 torch tensor with zeroed halos (bit-identical
+    storage; torch has no arithmetic on uint16 but none is needed)."""
+    import numpy as np
+    import torch
+
+    rows, w = cfa_band.shape
+    pad = np.zeros((rows + 2 * HALO, w), np.uint16)
+    pad[HALO:HALO + rows] = cfa_band
+    t = torch.from_numpy(pad.view(np.int16))
+    return t.to(device) if device is not None else t

@@ -1,0 +1,283 @@
+"""Parity of the gfx950 kernels with the oracle, through the C ABI (run on the GPU box: -m gpu).
+
+Tolerance (BASELINE.json north_star): <= 1 ULP per channel against the correctly rounded oracle,
+bit-exact for the integer stages.  Because the kernels evaluate the transcendentals to < 2^-49 and
+round once, the expectation is in fact bit-for-bit equality; `assert_parity` enforces the 1-ULP
+bound and, on the small cases, exact equality.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import rawphotoforge_amd as R
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL_ULP = 1
+
+
+def assert_parity(got, want, exact=True):
+    got = np.asarray(got, np.float32).reshape(want.shape)
+    d = util.ulp_diff(got, want)
+    if exact:
+        assert d.max() == 0, f"{int((d > 0).sum())} of {d.size} values differ, max {int(d.max())} ulp"
+    else:
+        assert d.max() <= TOL_ULP, f"max {int(d.max())} ulp, {int((d > 0).sum())} of {d.size} differ"
+
+
+def bayer_editor(gpu, cfa, rp):
+    return R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+
+
+# ---- BASELINE config 2: demosaic only ---------------------------------------------------------
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("shape", [(64, 64), (67, 130), (19, 257), (3, 3), (8, 5), (301, 6)])
+def test_demosaic_bit_exact(gpu, shape, variant):
+    gpu.set_kernel_variant(variant)
+    try:
+        for pat in (O.CFA_RGGB, O.CFA_BGGR, O.CFA_GRBG, O.CFA_GBRG):
+            cfa = util.bayer_uniform(*shape, seed=100 + pat)
+            rp = O.RawParams(cfa_pattern=pat, black=(500, 520, 530, 510), wb=(2.1, 1.0, 1.02, 1.6))
+            ed = bayer_editor(gpu, cfa, rp)
+            assert_parity(ed.rgba(), O.demosaic(cfa, rp))   # image before apply = linear frame
+    finally:
+        gpu.set_kernel_variant(0)
+
+
+def test_demosaic_saturated_and_below_black(gpu):
+    cfa = util.bayer_uniform(40, 72)
+    cfa[::3, ::5] = 0
+    cfa[1::4, 2::7] = 65535
+    rp = util.raw_params()
+    assert_parity(bayer_editor(gpu, cfa, rp).rgba(), O.demosaic(cfa, rp))
+
+
+# ---- BASELINE config 3: fused full chain ------------------------------------------------------
+GOLD = np.load(os.path.join(util.GOLDEN, "chain_golden.npz"))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("pname", ["D", "S"])
+@pytest.mark.parametrize("tag", ["U", "N"])
+def test_develop_matches_committed_golden(gpu, tag, pname, variant):
+    gpu.set_kernel_variant(variant)
+    try:
+        cfa = GOLD[f"cfa64_{tag}"]
+        p = util.params_D() if pname == "D" else util.params_S()
+        ed = bayer_editor(gpu, cfa, util.raw_params())
+        util.configure_editor(ed, p)
+        ed.apply_adjustments()
+        assert_parity(ed.rgba(), GOLD[f"develop64_{tag}_{pname}"])
+        big = (util.bayer_uniform if tag == "U" else util.bayer_natural)(256, 256)
+        ed = bayer_editor(gpu, big, util.raw_params())
+        util.configure_editor(ed, p)
+        ed.apply_adjustments()
+        digest = np.frombuffer(hashlib.sha256(ed.to_flat_vec_rgba().tobytes()).digest(), np.uint8)
+        assert np.array_equal(digest, GOLD[f"sha256_develop256_{tag}_{pname}"])
+    finally:
+        gpu.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("shape", [(33, 47), (129, 131), (16, 1000), (500, 9)])
+def test_develop_ragged_sizes_general_curves(gpu, shape):
+    cfa = util.bayer_natural(*shape)
+    rp = O.RawParams(cfa_pattern=O.CFA_GBRG)
+    p = util.params_G()
+    p.vignette = 45
+    ed = bayer_editor(gpu, cfa, rp)
+    util.configure_editor(ed, p)
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), O.develop(cfa, rp, [p]))
+
+
+def test_develop_with_user_masks(gpu):
+    h, w = 70, 150
+    cfa = util.bayer_uniform(h, w)
+    rp = util.raw_params()
+    rng = np.random.default_rng(8)
+    main, a, b = util.params_S(), util.params_G(), O.EditParameters(exposure=1.0, contrast=40, wb_temperature=60)
+    b.lightness_tone_curve = np.full(65536, 20000, np.int32)
+    ma = (rng.random((h, w)) > 0.4).astype(np.float32) * rng.choice([1.0, 0.7], (h, w)).astype(np.float32)
+    mb = np.zeros((h, w), np.float32)
+    mb[10:50, 20:120] = 1.0
+    ed = bayer_editor(gpu, cfa, rp)
+    ed.add_mask("a", ma)
+    ed.add_mask("b", mb)
+    util.configure_editor(ed, main)
+    util.configure_editor(ed, a, "a", main=False)
+    util.configure_editor(ed, b, "b", main=False)
+    ed.apply_adjustments()
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(ma), O.binarize_mask(mb)])
+    want = O.develop(cfa, rp, [main, a, b], masks=masks)
+    assert_parity(ed.rgba(), want)
+    ed.remove_mask("a")
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), O.develop(cfa, rp, [main, b], masks=masks[[0, 2]]))
+    ed.reset()
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), O.develop(cfa, rp, [O.EditParameters()]))
+
+
+def test_fused_equals_demosaic_then_apply(gpu):
+    cfa = util.bayer_natural(96, 200)
+    rp = util.raw_params()
+    p = util.params_S()
+    fused = bayer_editor(gpu, cfa, rp)
+    util.configure_editor(fused, p)
+    fused.apply_adjustments()
+    lin = bayer_editor(gpu, cfa, rp).rgba()
+    two = R.PhotoEditor.new_from_rgb_f32(gpu, lin[..., :3].copy(), 96, 200)
+    util.configure_editor(two, p)
+    two.apply_adjustments()
+    assert np.array_equal(fused.to_flat_vec_rgba(), two.to_flat_vec_rgba())
+
+
+# ---- the reference-equivalent back half (wgsl main on RGBA32F) -------------------------------
+def _rgb_image(h, w, seed=3):
+    rng = np.random.default_rng(seed)
+    img = rng.random((h, w, 3), dtype=np.float32) * np.float32(1.2) - np.float32(0.05)
+    img[0, :8] = 0
+    img[1, :8] = rng.random((8, 1), dtype=np.float32)
+    return img
+
+
+@pytest.mark.parametrize("pname", ["D", "S", "G"])
+def test_apply_rgb_editor(gpu, pname):
+    h, w = 61, 83
+    img = _rgb_image(h, w)
+    p = {"D": util.params_D, "S": util.params_S, "G": util.params_G}[pname]()
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    assert np.array_equal(ed.to_flat_vec_rgb().reshape(h, w, 3), img)      # image.rs:135-139, 202-277
+    assert (ed.rgba()[..., 3] == 1).all()
+    util.configure_editor(ed, p)
+    ed.apply_adjustments()
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    want = O.apply(rgba, [p])
+    assert_parity(ed.rgba(), want)
+    assert np.array_equal(ed.to_flat_vec_rgb().reshape(h, w, 3), want[..., :3])
+    assert np.array_equal(ed.to_rgb_array3_u8(), O.rgba_to_rgb_u8(want))   # image.rs:375-383
+
+
+@pytest.mark.parametrize("dist", [-100, -20, 35, 100])
+def test_lens_distortion(gpu, dist):
+    h, w = 90, 140
+    img = _rgb_image(h, w, seed=5)
+    p = util.params_S()
+    p.lens_distortion = dist
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    util.configure_editor(ed, p)
+    ed.apply_adjustments()
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    assert_parity(ed.rgba(), O.apply(rgba, [p]))
+    # Bayer source: demosaic pass + resampling pass
+    cfa = util.bayer_natural(h, w)
+    eb = bayer_editor(gpu, cfa, util.raw_params())
+    util.configure_editor(eb, p)
+    eb.apply_adjustments()
+    assert_parity(eb.rgba(), O.develop(cfa, util.raw_params(), [p]))
+
+
+def test_apply_is_repeatable_and_tracks_setters(gpu):
+    img = _rgb_image(32, 40)
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, 32, 40)
+    rgba = np.concatenate([img, np.ones((32, 40, 1), np.float32)], -1)
+    for p in (util.params_S(), util.params_D(), util.params_G(), util.params_S()):
+        util.configure_editor(ed, p)
+        ed.apply_adjustments()
+        first = ed.to_flat_vec_rgba()
+        ed.apply_adjustments()                     # non-destructive: always from original_image (lib.rs:507-515)
+        assert np.array_equal(first, ed.to_flat_vec_rgba())
+        assert_parity(first, O.apply(rgba, [p]))
+
+
+# ---- device-pointer layer: row tiles with halos, output formats -------------------------------
+def test_row_tiles_with_halo_equal_whole_frame(gpu):
+    torch = pytest.importorskip("torch")
+    h, w = 150, 260
+    cfa = util.bayer_uniform(h, w)
+    rp = util.raw_params()
+    p = util.params_S()
+    want = O.develop(cfa, rp, [p])
+    bounds = [0, 37, 38, 100, 150]   # odd offsets and a 1-row band on purpose
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    for y0, y1 in zip(bounds[:-1], bounds[1:]):
+        rows = y1 - y0
+        band = torch.from_numpy(pad[y0:y0 + rows + 4].copy().view(np.int16)).cuda()   # rows y0-2 .. y1+1
+        out = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
+        ed = R.PhotoEditor.for_tile(gpu, w, h, y0, rows)
+        util.configure_editor(ed, p)
+        ed.dev_develop(band.data_ptr(), util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32,
+                       torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert_parity(out.cpu().numpy(), want[y0:y1])
+        lin = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
+        R.dev_demosaic(gpu, band.data_ptr(), util.to_raw(rp), w, h, y0, rows, lin.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert_parity(lin.cpu().numpy(), O.demosaic(cfa, rp, y0=y0, rows=rows))
+
+
+def test_output_formats_of_the_fused_kernel(gpu):
+    torch = pytest.importorskip("torch")
+    h, w = 64, 200
+    cfa = util.bayer_natural(h, w)
+    rp = util.raw_params()
+    p = util.params_S()
+    want = O.develop(cfa, rp, [p])
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    d = torch.from_numpy(pad.view(np.int16)).cuda()
+    ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+    util.configure_editor(ed, p)
+    s = torch.cuda.current_stream().cuda_stream
+    rgb = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    ed.dev_develop(d.data_ptr(), util.to_raw(rp), rgb.data_ptr(), R.OUT_RGB_F32, s)
+    u8 = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    ed.dev_develop(d.data_ptr(), util.to_raw(rp), u8.data_ptr(), R.OUT_RGB_U8, s)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb.cpu().numpy(), want[..., :3])
+    assert np.array_equal(u8.cpu().numpy(), O.rgba_to_rgb_u8(want))
+
+
+# ---- BASELINE full size: size-independent properties + oracle on sampled bands ---------------
+def test_full_size_6000x4000(gpu):
+    torch = pytest.importorskip("torch")
+    h, w = 4000, 6000
+    cfa = util.bayer_uniform(h, w)
+    rp = util.raw_params()
+    s = torch.cuda.current_stream().cuda_stream
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    d = torch.from_numpy(pad.view(np.int16)).cuda()
+    for p in (util.params_D(), util.params_S()):
+        ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+        util.configure_editor(ed, p)
+        fused = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        ed.dev_develop(d.data_ptr(), util.to_raw(rp), fused.data_ptr(), R.OUT_RGBA_F32, s)
+        # (1) fused pass == demosaic pass followed by the reference-equivalent pass
+        lin = torch.empty_like(fused)
+        R.dev_demosaic(gpu, d.data_ptr(), util.to_raw(rp), w, h, 0, h, lin.data_ptr(), s)
+        two = torch.empty_like(fused)
+        ed.dev_apply(lin.data_ptr(), two.data_ptr(), R.OUT_RGBA_F32, s)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, two)
+        # (2) two row bands with halos == the whole frame
+        half = 1998
+        for y0, rows in ((0, half), (half, h - half)):
+            band = d[y0:y0 + rows + 4].contiguous()
+            eb = R.PhotoEditor.for_tile(gpu, w, h, y0, rows)
+            util.configure_editor(eb, p)
+            ob = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
+            eb.dev_develop(band.data_ptr(), util.to_raw(rp), ob.data_ptr(), R.OUT_RGBA_F32, s)
+            torch.cuda.synchronize()
+            assert torch.equal(ob, fused[y0:y0 + rows])
+        # (3) oracle on three 8-row bands (top edge, middle, bottom edge)
+        host = fused.cpu().numpy()
+        assert (host[..., 3] == 1).all() and host[..., :3].min() >= 0 and host[..., :3].max() <= 1
+        for y0 in (0, 1996, h - 8):
+            assert_parity(host[y0:y0 + 8], O.develop(cfa, rp, [p], y0=y0, rows=8))

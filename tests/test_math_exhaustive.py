@@ -1,0 +1,87 @@
+"""The transcendental code the kernels run (rpf_math.h, IEEE-only, hence bit-identical on host and
+device) against the oracle's correctly rounded builtins — exhaustively where the domain allows."""
+import ctypes as C
+import struct
+
+import numpy as np
+
+import oracle as O
+from tests import util
+
+
+def _bits(f):
+    return struct.unpack("I", struct.pack("f", f))[0]
+
+
+def _sweep(which, y, lo, hi):
+    tw, orc = util.twin(), O.lib()
+    b0, b1 = _bits(lo), _bits(hi)
+    bad, chunk = [], 1 << 24
+    for s in range(b0, b1, chunk):
+        n = min(chunk, b1 - s)
+        a, b = np.empty(n, np.float32), np.empty(n, np.float32)
+        tw.twin_pow_range(C.c_int(which), C.c_uint32(s), C.c_uint32(n), a.ctypes.data_as(C.c_void_p))
+        orc.orc_cr_powf_range(C.c_uint32(s), C.c_uint32(n), C.c_float(y), b.ctypes.data_as(C.c_void_p))
+        bad += [s + int(i) for i in np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]]
+    return b1 - b0, bad
+
+
+def test_pow_one_third_every_float_in_the_lms_domain():
+    # lms = M1 * rgb with rgb = k/65535: 0 or within [2^-21, 1.0000001]  (wgsl:65-67)
+    n, bad = _sweep(0, float(np.float32(1.0 / 3.0)), 2.0 ** -21, 1.25)
+    assert n > 170_000_000 and bad == []
+
+
+def test_pow_inv_2p4_every_float_in_the_gamma_domain():
+    # linear_to_srgb takes the pow branch above 0.0031308 > 2^-9 (wgsl:95-103); > 1 clamps to 1 afterwards
+    n, bad = _sweep(1, float(np.float32(1.0 / 2.4)), 2.0 ** -9, 8.0)
+    assert n > 100_000_000 and bad == []
+
+
+def test_pow_edge_cases():
+    tw = util.twin()
+    assert tw.twin_pow_cbrt(0.0) == 0.0 and tw.twin_pow_gamma(0.0) == 0.0
+    for x in (1e-30, 1e-12, 3e-39, 1e20, 3e38):   # outside the table: slow path, still within 1 ulp
+        for f, c in ((tw.twin_pow_cbrt, np.float32(1 / 3)), (tw.twin_pow_gamma, np.float32(1 / 2.4))):
+            assert util.ulp_diff(np.float32(f(x)), np.float32(O.lib().orc_cr_powf(x, float(c)))) <= 1
+
+
+def test_sincos_every_reachable_hue():
+    tw, orc = util.twin(), O.lib()
+    a, b, c, d = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    for k in range(65536):
+        tw.twin_sincos_hue(C.c_uint32(k), C.byref(a), C.byref(b))
+        orc.orc_hue_sincos(C.c_uint32(k), C.byref(c), C.byref(d))
+        assert (a.value, b.value) == (c.value, d.value), k
+
+
+def test_division_by_constant_every_k():
+    tw = util.twin()
+    k = np.arange(65536, dtype=np.float32)
+    for d in (65535.0, 32767.5):
+        want = k / np.float32(d)
+        got = np.array([tw.twin_div_u16(int(i), d) for i in range(65536)], np.float32)
+        assert np.array_equal(got, want)
+
+
+def test_atan2_random_and_special():
+    tw, orc = util.twin(), O.lib()
+    rng = np.random.default_rng(3)
+    n = 200_000
+    ys = (rng.standard_normal(n) * 10 ** rng.uniform(-9, 1, n)).astype(np.float32)
+    xs = (rng.standard_normal(n) * 10 ** rng.uniform(-9, 1, n)).astype(np.float32)
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        assert tw.twin_atan2(y, x) == orc.orc_cr_atan2f(y, x), (y, x)
+    t = float(np.float32(0.41421356))
+    for y, x in [(0, 0), (0, -0.0), (-0.0, 0.0), (-0.0, -0.0), (1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1),
+                 (1e-20, 1), (1, 1e-20), (3e-39, 1e-39), (float("inf"), 1), (1, float("inf")), (t, 1), (1, t),
+                 (1e38, 1e38), (-1e-31, 2e-31)]:
+        g, w = tw.twin_atan2(y, x), orc.orc_cr_atan2f(y, x)
+        assert g == w and np.signbit(g) == np.signbit(w), (y, x, g, w)
+
+
+def test_pow_1p5_sampled():
+    tw, orc = util.twin(), O.lib()
+    rng = np.random.default_rng(4)
+    for x in np.concatenate([rng.random(100_000).astype(np.float32), np.float32([0, 1, 1e-10, 0.25])]).tolist():
+        assert tw.twin_pow_1p5(x) == orc.orc_cr_powf(x, 1.5), x

@@ -1,0 +1,69 @@
+"""The N > 1 path on CPU: world_size 2 and 3 over gloo.  Each rank holds a row band of one frame,
+exchanges 2-row Bayer halos with its neighbours (rawphotoforge_amd.tiles.exchange_halos — the same code
+bench.py runs over RCCL) and the oracle run on every band buffer must reproduce the whole-frame result."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from rawphotoforge_amd import tiles  # noqa: E402
+
+H, W = 46, 40
+
+
+def _worker(rank, world, rdzv, out_dir):
+    import oracle as O
+    from tests import util
+    dist.init_process_group("gloo", init_method=f"file://{rdzv}", rank=rank, world_size=world)
+    try:
+        cfa = util.bayer_uniform(H, W, seed=99)
+        bands = tiles.split_rows(H, world)
+        y0, rows = bands[rank]
+        band = tiles.make_band_buffer(cfa[y0:y0 + rows])
+        before = band.clone()
+        tiles.exchange_halos(band, rank, world)
+        got = band.numpy().view(np.uint16)
+        # own rows untouched, interior halos == the neighbours' edge rows, frame-edge halos untouched
+        assert np.array_equal(got[2:-2], cfa[y0:y0 + rows])
+        if rank > 0:
+            assert np.array_equal(got[:2], cfa[y0 - 2:y0])
+        else:
+            assert np.array_equal(got[:2], before.numpy().view(np.uint16)[:2])
+        if rank < world - 1:
+            assert np.array_equal(got[-2:], cfa[y0 + rows:y0 + rows + 2])
+        # the band buffer alone reproduces the whole-frame result on its rows
+        virt = np.zeros((H, W), np.uint16)
+        lo, hi = max(y0 - 2, 0), min(y0 + rows + 2, H)
+        virt[lo:hi] = got[lo - (y0 - 2):hi - (y0 - 2)]
+        p = util.params_S()
+        mine = O.develop(virt, util.raw_params(), [p], y0=y0, rows=rows)
+        np.save(os.path.join(out_dir, f"band{rank}.npy"), mine)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_reproduces_whole_frame(world):
+    import oracle as O
+    from tests import util
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, os.path.join(d, "rdzv"), d), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"band{r}.npy")) for r in range(world)]
+    whole = O.develop(util.bayer_uniform(H, W, seed=99), util.raw_params(), [util.params_S()])
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+def test_split_rows():
+    for h, n in ((4000, 8), (8000, 8), (4002, 3), (46, 3), (16, 8)):
+        bands = tiles.split_rows(h, n)
+        assert bands[0][0] == 0 and sum(r for _, r in bands) == h
+        assert all(y % 2 == 0 for y, _ in bands) and all(r >= 2 for _, r in bands)
+        assert all(bands[i][0] + bands[i][1] == bands[i + 1][0] for i in range(n - 1))
+    with pytest.raises(ValueError):
+        tiles.split_rows(6, 4)

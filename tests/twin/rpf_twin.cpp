@@ -76,3 +76,35 @@ void twin_edit_chain(const float* rgb, size_t npix, const rpf::MaskParams* mp, u
 
 size_t twin_sizeof_mask_params(void) { return sizeof(rpf::MaskParams); }
 }
+
+// ---- whole-chain twin driven from reference-style EditParameters ------------------------------
+#include "../../rawphotoforge_amd/csrc/rpf_host.h"
+
+extern "C" {
+
+struct twin_edit_params {  // same layout as oracle's orc_edit_params
+    float exposure;
+    int32_t contrast, shadow, highlight, black, white, wb_temperature, wb_tint, vignette, lens_distortion;
+    float mask_range;
+};
+
+// rgb: npix x 3 linear input; luts: num_masks x 65536 each.  Runs make_mask_params (the product's
+// host code) + edit_chain (the kernels' arithmetic) on the CPU.
+void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint32_t num_masks,
+                const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
+                float* rgba_out)
+{
+    std::vector<rpf::MaskParams> mp(num_masks);
+    for (uint32_t m = 0; m < num_masks; ++m) {
+        rpf::EditParameters p;
+        p.exposure = ep[m].exposure; p.contrast = ep[m].contrast; p.shadow = ep[m].shadow;
+        p.highlight = ep[m].highlight; p.black = ep[m].black; p.white = ep[m].white;
+        p.wb_temperature = ep[m].wb_temperature; p.wb_tint = ep[m].wb_tint;
+        const int32_t* src[4] = {bright, hue, sat, light};
+        for (int c = 0; c < 4; ++c)
+            p.curve[c].assign(src[c] + (size_t)m * RPF_CURVE_RESOLUTION, src[c] + (size_t)(m + 1) * RPF_CURVE_RESOLUTION);
+        mp[m] = rpf::make_mask_params(p);
+    }
+    twin_edit_chain(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
+}
+}

@@ -1,0 +1,132 @@
+"""Shared helpers of the test-suite: synthetic inputs, parameter sets,
+ULP distance, the CPU twin loader.  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TWIN_SRC = os.path.join(ROOT, "tests", "twin", "rpf_twin.cpp")
+TWIN_LIB = os.path.join(ROOT, "tests", "twin", "librpf_twin.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def build_twin(force=False) -> str:
+    deps = [TWIN_SRC] + [os.path.join(ROOT, "rawphotoforge_amd", "csrc", f)
+                         for f in ("rpf_math.h", "rpf_chain.h", "rpf_host.h", "rpf_tables.cpp")]
+    if not force and os.path.exists(TWIN_LIB) and all(os.path.getmtime(TWIN_LIB) >= os.path.getmtime(d) for d in deps):
+        return TWIN_LIB
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared",
+                    "-I/opt/rocm/include", "-o", TWIN_LIB, TWIN_SRC,
+                    os.path.join(ROOT, "rawphotoforge_amd", "csrc", "rpf_tables.cpp"), "-lm"], check=True)
+    return TWIN_LIB
+
+
+_twin = None
+
+
+def twin():
+    global _twin
+    if _twin is None:
+        _twin = C.CDLL(build_twin())
+        for n in ("twin_pow_cbrt", "twin_pow_gamma", "twin_pow_1p5", "twin_hue_angle"):
+            getattr(_twin, n).restype = C.c_float
+        _twin.twin_pow_cbrt.argtypes = [C.c_float]
+        _twin.twin_pow_gamma.argtypes = [C.c_float]
+        _twin.twin_pow_1p5.argtypes = [C.c_float]
+        _twin.twin_atan2.restype = C.c_float
+        _twin.twin_atan2.argtypes = [C.c_float, C.c_float]
+        _twin.twin_div_u16.restype = C.c_float
+        _twin.twin_div_u16.argtypes = [C.c_uint32, C.c_float]
+    return _twin
+
+
+def twin_apply(rgb, masks_params) -> np.ndarray:
+    """Device arithmetic (rpf_chain.h) + the product's host parameter packing, on the CPU."""
+    n = len(masks_params)
+    a = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+    ep = (O.EditParamsC * n)(*[p.to_c() for p in masks_params])
+    luts = [np.stack([np.asarray(getattr(p, nm), np.int32) for p in masks_params])
+            for nm in ("brightness_tone_curve", "hue_tone_curve", "saturation_tone_curve", "lightness_tone_curve")]
+    out = np.empty((a.shape[0], 4), np.float32)
+    twin().twin_apply(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.shape[0]), ep, C.c_uint32(n),
+                      *[l.ctypes.data_as(C.c_void_p) for l in luts], out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def ulp_diff(a, b) -> np.ndarray:
+    """Distance in units in the last place between two float32 arrays (monotone integer mapping)."""
+    def key(x):
+        i = np.ascontiguousarray(x, np.float32).view(np.int32).astype(np.int64)
+        return np.where(i < 0, -(i & 0x7FFFFFFF), i)
+    return np.abs(key(a) - key(b))
+
+
+# ---- synthetic inputs and parameter sets, SURVEY.md §8(d) --------------------------------------
+from rawphotoforge_amd import synthetic as syn  # noqa: E402  (pure numpy; shared with bench.py)
+
+BLACK, WHITE = syn.BLACK, syn.WHITE
+bayer_uniform = syn.bayer_uniform
+bayer_natural = syn.bayer_natural
+
+
+def raw_params(pattern=O.CFA_RGGB) -> O.RawParams:
+    r = dict(syn.RAW)
+    r["cfa_pattern"] = pattern
+    return O.RawParams(**r)
+
+
+def oracle_params(spec: dict) -> O.EditParameters:
+    """The oracle's EditParameters for a synthetic.PARAM_SETS entry (curves through the ORACLE's PCHIP)."""
+    scalars = {k: v for k, v in spec.items() if k not in ("brightness", "hue", "saturation", "lightness")}
+    p = O.EditParameters(**scalars)
+    for name in ("brightness", "hue", "saturation", "lightness"):
+        c = spec.get(name)
+        if c is None:
+            continue
+        if c[0] == "points":
+            v = O.curve_from_control_points(c[1], c[2])
+        elif c[0] == "const":
+            v = np.full(O.CURVE_RESOLUTION, c[1], np.int32)
+        else:
+            v = np.asarray(c[1], np.int32)
+        setattr(p, name + "_tone_curve", v)
+    return p
+
+
+def params_D() -> O.EditParameters:
+    """Set D: reference defaults (lib.rs:44-64)."""
+    return oracle_params(syn.PARAM_SETS["D"])
+
+
+def params_S() -> O.EditParameters:
+    """Set S (stress), SURVEY.md §8(d)."""
+    return oracle_params(syn.PARAM_SETS["S"])
+
+
+def params_G() -> O.EditParameters:
+    """General: every curve non-trivial (hue/sat/light from PCHIP, brightness arbitrary incl. out-of-range)."""
+    return oracle_params(syn.PARAM_SETS["G"])
+
+
+def configure_editor(ed, p: O.EditParameters, mask_name=None, main=True):
+    """Drive the product's setters from an oracle EditParameters (like web/main.ts:809-826)."""
+    ed.set_whitebalance(p.wb_temperature, p.wb_tint, mask_name)
+    ed.set_tone(p.exposure, p.contrast, p.shadow, p.highlight, p.black, p.white, mask_name)
+    if main:
+        ed.set_vignette(p.vignette)
+        ed.set_lens_distortion_correction(p.lens_distortion)
+    ed.set_brightness_tone_curve(curve=p.brightness_tone_curve, mask_name=mask_name)
+    ed.set_oklch_hue_curve(curve=p.hue_tone_curve, mask_name=mask_name)
+    ed.set_oklch_saturation_curve(curve=p.saturation_tone_curve, mask_name=mask_name)
+    ed.set_oklch_lightness_curve(curve=p.lightness_tone_curve, mask_name=mask_name)
+
+
+def to_raw(rp: O.RawParams):
+    import rawphotoforge_amd as R
+    return R.RawParams(rp.cfa_pattern, rp.black, rp.white, rp.wb, rp.cam2rgb)
