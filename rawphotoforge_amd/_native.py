@@ -103,6 +103,31 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One process, one HIP runtime.  A ROCm PyTorch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, requested by torch under the name "libamdhip64.so"), while librpf_hip.so asks the
+    loader for "libamdhip64.so.7" — loaded in that order the process ends up with two runtimes and the
+    second one sees no GPU.  If torch is installed but not imported yet, map ITS copy first (by path, no
+    torch import): librpf_hip.so then resolves to it by SONAME and a later `import torch` finds it loaded."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch's runtime is already mapped; ours resolves to it by SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     """Load librpf_hip.so; raise if it was not built (python -m rawphotoforge_amd.build)."""
     global _lib
@@ -111,6 +136,7 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is not built and there is no CPU fallback. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` or `python rawphotoforge_amd/build.py`.")
+        _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError here = header/library drift: fail loudly

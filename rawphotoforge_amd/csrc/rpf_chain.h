@@ -208,19 +208,18 @@ RPF_HD void edit_chain(float r, float g, float b, uint32_t active, const MaskPar
     const float l = RPF_F(0.4122214708) * r + RPF_F(0.5363325363) * g + RPF_F(0.0514459929) * b;
     const float mm = RPF_F(0.2119034982) * r + RPF_F(0.6806995451) * g + RPF_F(0.1073969566) * b;
     const float s = RPF_F(0.0883024619) * r + RPF_F(0.2817188376) * g + RPF_F(0.6299787005) * b;
-    const float lc = powc(l > 0.0f ? l : 0.0f, T.cbrt);
-    const float mc = powc(mm > 0.0f ? mm : 0.0f, T.cbrt);
-    const float sc = powc(s > 0.0f ? s : 0.0f, T.cbrt);
+    const float lc = powc<POW_CBRT>(l > 0.0f ? l : 0.0f, T.cbrt);
+    const float mc = powc<POW_CBRT>(mm > 0.0f ? mm : 0.0f, T.cbrt);
+    const float sc = powc<POW_CBRT>(s > 0.0f ? s : 0.0f, T.cbrt);
     float L = RPF_F(0.2104542553) * lc + RPF_F(0.7936177850) * mc + RPF_F(-0.0040720468) * sc;
     const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
     const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;
     float C = __builtin_sqrtf(A * A + Bq * Bq);
-    float h = atan2_cr(Bq, A) / RPF_K_TWO_PI_F;
+    float h = div_by_const(atan2_cr(Bq, A), RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F));
     if (h < 0.0f) h += 1.0f;
 
     // per-mask OKLCH curves, wgsl:312-331
     uint32_t hue_k = 0;
-    bool quantised = false;
     for (uint32_t m = 0; m < num_masks; ++m) {
         if (!((active >> m) & 1u)) continue;
         const MaskParams& P = mp[m];
@@ -231,19 +230,15 @@ RPF_HD void edit_chain(float r, float g, float b, uint32_t active, const MaskPar
             (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST))
             luts.hsl(m, hu, P, nh, sat_gain, light_gain);
         hue_k = nh;
-        quantised = true;
         h = div_u16_by(nh, 65535.0f, inv65535);
         C = C * sat_gain;
         L = L * light_gain;
     }
 
-    // oklch_to_linear_srgb, wgsl:77-84
+    // oklch_to_linear_srgb, wgsl:77-84.  "main" (bit 0) is all ones by construction (lib.rs:193-196), so
+    // the hue reaching here is always k/65535 for the integer k the last active mask fetched.
     float cs, sn;
-    if (quantised) {
-        sincos_hue(hue_k, T.sc, cs, sn);
-    } else {  // no active mask at this pixel: only reachable if "main" were not all ones
-        slow_sincosf((h * 2.0f) * RPF_K_PI_F, cs, sn);
-    }
+    sincos_hue(hue_k, T.sc, cs, sn);
     const float oa = C * cs, ob = C * sn;
     const float l_ = RPF_F(1.0) * L + RPF_F(0.3963377774) * oa + RPF_F(0.2158037573) * ob;
     const float m_ = RPF_F(1.0) * L + RPF_F(-0.1055613458) * oa + RPF_F(-0.0638541728) * ob;
@@ -258,8 +253,8 @@ RPF_HD void edit_chain(float r, float g, float b, uint32_t active, const MaskPar
     float out[3];
     for (int k = 0; k < 3; ++k) {
         const float c = lin[k];
-        const float v = c <= RPF_F(0.0031308) ? c * RPF_F(12.92)
-                                              : RPF_F(1.055) * powc(c, T.gamma) - RPF_F(0.055);
+        const float hi = RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - RPF_F(0.055);  // unused when c <= thr
+        const float v = c <= RPF_F(0.0031308) ? c * RPF_F(12.92) : hi;
         out[k] = clampf(v, 0.0f, 1.0f);
     }
     o0 = out[0]; o1 = out[1]; o2 = out[2];

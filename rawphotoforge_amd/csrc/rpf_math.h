@@ -1,5 +1,5 @@
 // rpf_math.h — correctly rounded binary32 pow / atan2 / sincos for the edit chain,
-// written with IEEE-754 operations only (binary64 fma/mul/add, binary32 div), so a
+// written with IEEE-754 operations only (binary64 fma/mul/add/ldexp, binary32 div), so a
 // host build of this header computes bit-for-bit what the gfx950 kernels compute.
 //
 // Why: WGSL leaves pow/atan2/sin/cos accuracy to the backend
@@ -10,6 +10,7 @@
 // after it — so the kernels evaluate each transcendental in binary64 to < 2^-49
 // relative and round once.  The two pow domains that matter are small enough to
 // be checked exhaustively against the oracle (tests/test_math_exhaustive.py).
+// Everything here is branch-free (selects only): no divergence, no calls.
 #pragma once
 #include <stdint.h>
 
@@ -28,24 +29,36 @@ namespace rpf {
 // ---------------------------------------------------------------------------
 
 // x^c = 2^(e c) * r_j^(-c) * (1 + t)^c,  x = 2^e m,  t = m r_j - 1 (exact in binary64)
+#define RPF_POW_EMIN (-160)  // covers every binary32 exponent, subnormals included (2^-149)
+#define RPF_POW_ECNT 288
 struct PowTable {
-    double E[64];        // E[e + 32] = 2^(e c),                 e in [-32, 31]
-    double TR[128][2];   // TR[j] = { r_j^(-c), r_j },          j = top 7 mantissa bits
-    double C[5];         // binomial(c, k), k = 1..5
-    float c;             // the binary32 exponent itself (slow path)
-    float pad;
+    double E[RPF_POW_ECNT];  // E[e - EMIN] = 2^(e c)
+    double TR[128][2];       // TR[j] = { r_j^(-c), r_j },  j = top 7 mantissa bits
 };
 
 // cos/sin of k * K_HUE_STEP split as k = 256 k1 + k0
 struct SinCosTable {
-    double hi[256][2];   // { cos, sin }(256 k1 * step)
-    double lo[256][2];   // { cos, sin }(k0 * step)
+    double hi[256][2];  // { cos, sin }(256 k1 * step)
+    double lo[256][2];  // { cos, sin }(k0 * step)
 };
 
 struct MathTables {
-    PowTable cbrt;       // c = f32(1/3)    wgsl:67
-    PowTable gamma;      // c = f32(1/2.4)  wgsl:98
+    PowTable cbrt;   // c = f32(1/3)    wgsl:67
+    PowTable gamma;  // c = f32(1/2.4)  wgsl:98
     SinCosTable sc;
+};
+
+// binomial(c, k), k = 1..5, for the two exponents (tools/gen_math_consts.py); compile-time
+// constants so they live in SGPRs / inline operands instead of LDS
+enum PowKind { POW_CBRT = 0, POW_GAMMA = 1 };
+template <int KIND> struct PowCoef;
+template <> struct PowCoef<POW_CBRT> {
+    static constexpr double c1 = 0x1.5555560000000p-2, c2 = -0x1.c71c7238e38e0p-4, c3 = 0x1.f9add40ca4583p-5,
+                            c4 = -0x1.511e8d48b0fcap-5, c5 = 0x1.ee71136534be7p-6;
+};
+template <> struct PowCoef<POW_GAMMA> {
+    static constexpr double c1 = 0x1.aaaaaa0000000p-2, c2 = -0x1.f1c71c38e38e0p-4, c3 = 0x1.06b74f00ca456p-4,
+                            c4 = -0x1.535770cc3f359p-5, c5 = 0x1.e663bb5d82900p-6;
 };
 
 // wgsl:78 `c.z * 2.0 * 3.14159265359`, wgsl:72 `2.0 * 3.14159265359`
@@ -59,56 +72,59 @@ RPF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
 RPF_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 RPF_HD uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 RPF_HD float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
-
-// Out-of-domain fallbacks (never reached by the edit chain's value ranges): kept out
-// of line so the hot loop stays small in the instruction cache.
-#if defined(__HIPCC__)
-#define RPF_NOINLINE __host__ __device__ __attribute__((noinline))
-#else
-#define RPF_NOINLINE __attribute__((noinline))
-#endif
-RPF_NOINLINE static float slow_powf(float x, float y) { return (float)::pow((double)x, (double)y); }
-RPF_NOINLINE static float slow_atan2f(float y, float x) { return (float)::atan2((double)y, (double)x); }
-RPF_NOINLINE static void slow_sincosf(float a, float& cs, float& sn)
-{
-    cs = (float)::cos((double)a);
-    sn = (float)::sin((double)a);
-}
+RPF_HD double hilo2d(uint32_t hi, uint32_t lo) { return u2d(((uint64_t)hi << 32) | lo); }
 
 // f32(k) / d for integer k in [0, 65535] and d in {65535, 32767.5}: q = k*r, one
 // fma residual, one fma correction.  Equal to the IEEE quotient for every k
 // (checked exhaustively in tests/test_math_exhaustive.py).  wgsl:303-305, 328-330.
 RPF_HD float div_u16_by(uint32_t k, float d, float rd)
 {
-    float kf = (float)k;
-    float q0 = kf * rd;
-    float e = __builtin_fmaf(-q0, d, kf);
+    const float kf = (float)k;
+    const float q0 = kf * rd;
+    const float e = __builtin_fmaf(-q0, d, kf);
     return __builtin_fmaf(e, rd, q0);
 }
 
-// Correctly rounded x^c for x >= 0 (c fixed by the table).  Exhaustively equal
-// to the oracle's cr_powf on [2^-21, 2) for cbrt and [2^-9, 2^3) for gamma.
-template <class TabT>
+// x / d for a constant d: Markstein's sequence (q = RN(x rd), r = fma(-q, d, x) exact,
+// q' = RN(q + r rd)) is the correctly rounded quotient when rd = RN(1/d) and d's significand
+// is not all ones — true for d = f32(2 pi) (wgsl:72) — as long as nothing underflows; below
+// 2^-100 the IEEE division is used instead (a rarely taken, wave-uniformly skipped branch).
+// Equal to IEEE division on the whole range of atan2 results (tests/test_math_exhaustive.py).
+RPF_HD float div_by_const(float x, float d, float rd)
+{
+    const float q0 = x * rd;
+    const float e = __builtin_fmaf(-q0, d, x);
+    float q = __builtin_fmaf(e, rd, q0);
+    if (__builtin_expect(__builtin_fabsf(x) < 0x1p-100f, 0)) q = x / d;
+    return q;
+}
+
+// Correctly rounded x^c for x >= 0 (c fixed by KIND).  Exhaustively equal to the oracle's
+// cr_powf on [2^-21, 1.25) for cbrt and [2^-9, 2^3) for gamma; same algorithm (rel. error
+// < 2^-50 before the single rounding) on the rest of the binary32 range.
+// x = 0 -> 0, x = +inf -> +inf, NaN -> NaN; x < 0 is the caller's business (unspecified).
+template <int KIND, class TabT>
 RPF_HD float powc(float x, const TabT& T)
 {
-    if (!(x > 0.0f)) return 0.0f;
     const double xd = (double)x;
     const uint64_t u = d2u(xd);
     const uint32_t hi = (uint32_t)(u >> 32);
-    const int e = (int)((hi >> 20) & 0x7ffu) - 1023;
+    const uint32_t ebits = (hi >> 20) & 0x7ffu;
     const uint32_t j = (hi >> 13) & 127u;
-    if ((uint32_t)(e + 32) >= 64u) return slow_powf(x, T.c);
-    const double m = u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    int ei = (int)ebits - (1023 + RPF_POW_EMIN);
+    ei = ei < 0 ? 0 : (ei > RPF_POW_ECNT - 1 ? RPF_POW_ECNT - 1 : ei);
+    const double m = hilo2d((hi & 0x000fffffu) | 0x3ff00000u, (uint32_t)u);
     const double r = T.TR[j][1];
     const double tj = T.TR[j][0];
     const double t = __builtin_fma(m, r, -1.0);
-    double p = __builtin_fma(t, T.C[4], T.C[3]);
-    p = __builtin_fma(t, p, T.C[2]);
-    p = __builtin_fma(t, p, T.C[1]);
-    p = __builtin_fma(t, p, T.C[0]);
+    using K = PowCoef<KIND>;
+    double p = __builtin_fma(t, K::c5, K::c4);
+    p = __builtin_fma(t, p, K::c3);
+    p = __builtin_fma(t, p, K::c2);
+    p = __builtin_fma(t, p, K::c1);
     p = __builtin_fma(t, p, 1.0);
-    const double y = (T.E[e + 32] * tj) * p;
-    return (float)y;
+    const float y = (float)((T.E[ei] * tj) * p);
+    return ebits == 0x7ffu ? x : (x > 0.0f ? y : 0.0f);
 }
 
 // atan(q) = q + q^3 P(q^2), |q| <= tan(pi/8); rel. error 2^-52.7 (tools/gen_math_consts.py)
@@ -128,34 +144,34 @@ RPF_HD double atan_small(double q)
     return __builtin_fma(q * s, p, q);
 }
 
-// atan2(y, x) rounded to binary32 from a binary64 value with rel. error < 2^-49.
+// atan2(y, x) for finite arguments, rounded to binary32 from a binary64 value with
+// rel. error < 2^-49.  Signed zeros as IEEE: atan2(+-0, +0) = +-0, atan2(+-0, -0) = +-pi.
 RPF_HD float atan2_cr(float y, float x)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
     const float mx = ax > ay ? ax : ay;
     const float mn = ax > ay ? ay : ax;
-    double r;
-    if (mx == 0.0f) {
-        r = 0.0;
-    } else if (!(mx < 1e37f) || mx < 1e-30f) {
-        return slow_atan2f(y, x);
-    } else {
-        const double dmx = (double)mx, dmn = (double)mn;
-        // theta in [0, pi/8]: q = mn/mx;  theta in (pi/8, pi/4]: pi/4 + atan((mn-mx)/(mn+mx))
-        const bool upper = mn > 0.41421356f * mx;
-        const double num = upper ? dmn - dmx : dmn;
-        const double den = upper ? dmn + dmx : dmx;
-        const float rc = 1.0f / (float)den;             // IEEE binary32 division
-        const double q0 = num * (double)rc;
-        const double res = __builtin_fma(-q0, den, num);
-        const double q = __builtin_fma(res, (double)rc, q0);  // rel. error ~2^-47 of a 2^-24 term
-        r = atan_small(q);
-        if (upper) r += 0x1.921fb54442d18p-1;          // pi/4
-        if (ay > ax) r = 0x1.921fb54442d18p+0 - r;      // pi/2 - r
-    }
-    if ((f2bits(x) >> 31) != 0u) r = 0x1.921fb54442d18p+1 - r;  // x < 0 or x == -0: pi - r
+    const double dmx = (double)mx, dmn = (double)mn;
+    // theta in [0, pi/8]: q = mn/mx;  theta in (pi/8, pi/4]: pi/4 + atan((mn-mx)/(mn+mx))
+    const bool upper = mn > 0.41421356f * mx;
+    const double num = upper ? dmn - dmx : dmn;
+    const double den = upper ? dmn + dmx : dmx;
+    // den = 2^E d1, d1 in [1, 2): the binary32 reciprocal below can neither overflow nor lose bits
+    const uint64_t ud = d2u(den);
+    const uint32_t dhi = (uint32_t)(ud >> 32);
+    const int E = (int)((dhi >> 20) & 0x7ffu) - 1023;
+    const double d1 = hilo2d((dhi & 0x000fffffu) | 0x3ff00000u, (uint32_t)ud);  // den == 0 -> 1.0, num == 0
+    const double n1 = __builtin_ldexp(num, -E);
+    const float rc = 1.0f / (float)d1;  // IEEE binary32 division, rel. error 2^-23
+    const double q0 = n1 * (double)rc;
+    const double res = __builtin_fma(-q0, d1, n1);
+    const double q = __builtin_fma(res, (double)rc, q0);  // rel. error ~2^-46 of a 2^-23 term
+    double r = atan_small(q);
+    r = upper ? r + 0x1.921fb54442d18p-1 : r;            // + pi/4
+    r = ay > ax ? 0x1.921fb54442d18p+0 - r : r;            // pi/2 - r
+    r = (f2bits(x) >> 31) ? 0x1.921fb54442d18p+1 - r : r;  // x < 0 or x == -0: pi - r
     const float rf = (float)r;
-    return bits2f(f2bits(rf) | (f2bits(y) & 0x80000000u));      // copysign(rf, y)
+    return bits2f(f2bits(rf) | (f2bits(y) & 0x80000000u));  // copysign(rf, y)
 }
 
 // cos(a), sin(a) for a = f32(f32(k)/65535) * 2 * f32(pi), k in [0, 65535] — the
@@ -171,7 +187,7 @@ RPF_HD void sincos_hue(uint32_t k, const TabT& S, float& cs, float& sn)
     const double c0 = S.lo[k & 255u][0], s0 = S.lo[k & 255u][1];
     const double ce = __builtin_fma(c1, c0, -(s1 * s0));
     const double se = __builtin_fma(s1, c0, c1 * s0);
-    const double q = __builtin_fma(-0.5 * delta, delta, 1.0);   // cos(delta) to 2^-80
+    const double q = __builtin_fma(-0.5 * delta, delta, 1.0);  // cos(delta) to 2^-80
     cs = (float)__builtin_fma(-se, delta, ce * q);
     sn = (float)__builtin_fma(ce, delta, se * q);
 }

@@ -9,7 +9,8 @@ namespace rpf {
 static void build_pow(PowTable& P, float cf)
 {
     const long double c = (long double)cf;
-    for (int e = -32; e < 32; ++e) P.E[e + 32] = (double)powl(2.0L, (long double)e * c);
+    for (int e = RPF_POW_EMIN; e < RPF_POW_EMIN + RPF_POW_ECNT; ++e)
+        P.E[e - RPF_POW_EMIN] = (double)powl(2.0L, (long double)e * c);
     for (int j = 0; j < 128; ++j) {
         const long double mid = 1.0L + ((long double)j + 0.5L) / 128.0L;
         // r_j: reciprocal of the bin centre on a 2^-16 grid, so m * r_j is exact in binary64
@@ -17,13 +18,6 @@ static void build_pow(PowTable& P, float cf)
         P.TR[j][1] = r;
         P.TR[j][0] = (double)powl((long double)r, -c);
     }
-    long double b = 1.0L;
-    for (int k = 1; k <= 5; ++k) {
-        b = b * (c - (long double)(k - 1)) / (long double)k;  // binomial(c, k)
-        P.C[k - 1] = (double)b;
-    }
-    P.c = cf;
-    P.pad = 0.0f;
 }
 
 void build_math_tables(MathTables& T)

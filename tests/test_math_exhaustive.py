@@ -85,3 +85,21 @@ def test_pow_1p5_sampled():
     rng = np.random.default_rng(4)
     for x in np.concatenate([rng.random(100_000).astype(np.float32), np.float32([0, 1, 1e-10, 0.25])]).tolist():
         assert tw.twin_pow_1p5(x) == orc.orc_cr_powf(x, 1.5), x
+
+
+def test_division_by_two_pi_every_atan2_result():
+    # Markstein sequence vs IEEE division for every binary32 in [0, 3.15] (atan2's range; the
+    # sequence is odd in x, so the negative half follows)
+    tw = util.twin()
+    d = np.float32(2.0 * 3.14159265359)
+    lo, hi, chunk = 0, _bits(3.15), 1 << 25
+    for s in range(lo, hi, chunk):
+        n = min(chunk, hi - s)
+        got = np.empty(n, np.float32)
+        tw.twin_div_two_pi_range(C.c_uint32(s), C.c_uint32(n), got.ctypes.data_as(C.c_void_p))
+        x = np.arange(s, s + n, dtype=np.uint32).view(np.float32)
+        assert np.array_equal(got.view(np.uint32), (x / d).view(np.uint32)), hex(s)
+    for x in (-1.0, -3.1415927, -1e-30, -1e-44):
+        tw.twin_div_two_pi.restype = C.c_float
+        tw.twin_div_two_pi.argtypes = [C.c_float]
+        assert np.float32(tw.twin_div_two_pi(x)) == np.float32(x) / d

@@ -35,12 +35,19 @@ struct HostLuts {
 
 extern "C" {
 
-float twin_pow_cbrt(float x) { return rpf::powc(x, tabs().cbrt); }
-float twin_pow_gamma(float x) { return rpf::powc(x, tabs().gamma); }
+float twin_pow_cbrt(float x) { return rpf::powc<rpf::POW_CBRT>(x, tabs().cbrt); }
+float twin_pow_gamma(float x) { return rpf::powc<rpf::POW_GAMMA>(x, tabs().gamma); }
 float twin_atan2(float y, float x) { return rpf::atan2_cr(y, x); }
 void twin_sincos_hue(uint32_t k, float* cs, float* sn) { rpf::sincos_hue(k, tabs().sc, *cs, *sn); }
 float twin_pow_1p5(float x) { return rpf::pow_1p5(x); }
 float twin_div_u16(uint32_t k, float d) { return rpf::div_u16_by(k, d, 1.0f / d); }
+float twin_div_two_pi(float x) { return rpf::div_by_const(x, RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F)); }
+void twin_div_two_pi_range(uint32_t bits_lo, uint32_t n, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i)
+        out[i] = twin_div_two_pi(rpf::bits2f(bits_lo + (uint32_t)i));
+}
 float twin_hue_angle(uint32_t k)
 {
     const float h = rpf::div_u16_by(k, 65535.0f, (float)(1.0 / 65535.0));
@@ -54,7 +61,7 @@ void twin_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < (long long)n; ++i) {
         float x = rpf::bits2f(bits_lo + (uint32_t)i);
-        out[i] = which == 0 ? rpf::powc(x, T.cbrt) : rpf::powc(x, T.gamma);
+        out[i] = which == 0 ? rpf::powc<rpf::POW_CBRT>(x, T.cbrt) : rpf::powc<rpf::POW_GAMMA>(x, T.gamma);
     }
 }
 
