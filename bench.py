@@ -136,6 +136,19 @@ def main():
                      "kernel_ms_avg": round(kern_avg_ms, 4), "bytes_per_px": bpp},
     }
 
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 wraps
+    # the command): they come from the FETCH_SIZE / WRITE_SIZE passes of the same command, summarised by
+    # tools/summarize_profiles.py into profiles/hbm_traffic.json (see profiles/*_summary.md).
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            tr = json.load(f).get(args.workload)
+        if tr and args.params == "D" and args.data == "U":
+            result["roofline"]["traffic"] = tr["traffic_bytes"]
+            result["roofline"]["traffic_unit"] = "HBM bytes per launch (algorithmic: %d)" % (bpp * rows * W)
+            result["roofline"]["traffic_source"] = tr["source"]
+    except (OSError, ValueError):
+        pass
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle as O   # the checker, timed as the reported CPU baseline (never on the GPU path)
         from tests import util
