@@ -161,103 +161,136 @@ RPF_HD void lens_sample(const Fetch& fetch, int w_u, int h_u, int x, int y, floa
 // ---------------------------------------------------------------------------
 #define RPF_F(x) ((float)(x))
 
-template <class Luts, class Tabs>
-RPF_HD void edit_chain(float r, float g, float b, uint32_t active, const MaskParams* mp, uint32_t num_masks,
-                       const Luts& luts, const Tabs& T, float& o0, float& o1, float& o2)
+// clamp for finite inputs: v_max_f32 / v_min_f32 on the device (full-rate), the oracle's
+// min(max(v, lo), hi) on the host; the two agree on every non-NaN value up to the sign of zero,
+// which no later operation of the chain observes.
+RPF_HD float clamp01(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f);
+#else
+    return clampf(v, 0.0f, 1.0f);
+#endif
+}
+
+// One mask's linear-RGB stage (wgsl:283-307) on N pixels in lockstep.  act == nullptr: the mask is
+// "main" (all ones); otherwise pixel n is updated only where act[n] is set (wgsl:281 `continue`).
+template <int N, class Luts>
+RPF_HD void mask_rgb_stage(const MaskParams& P, uint32_t m, const Luts& luts, float (&r)[N], float (&g)[N],
+                           float (&b)[N], const bool* act)
 {
     const float inv65535 = (float)(1.0 / 65535.0);
-    for (uint32_t m = 0; m < num_masks; ++m) {
-        if (!((active >> m) & 1u)) continue;
-        const MaskParams& P = mp[m];
-        r = r * P.r_gain; g = g * P.g_gain; b = b * P.b_gain;
+    for (int n = 0; n < N; ++n) {
+        float x = r[n] * P.r_gain, y = g[n] * P.g_gain, z = b[n] * P.b_gain;  // wgsl:285-288
         // tone(), wgsl:200-259
-        r *= P.exposure_mul; g *= P.exposure_mul; b *= P.exposure_mul;
-        const float luma = r * RPF_F(0.2126) + g * RPF_F(0.7152) + b * RPF_F(0.0722);
-        const float shadow_mask = clampf(1.0f - luma, 0.0f, 1.0f);
-        const float highlight_mask = clampf(luma, 0.0f, 1.0f);
+        x *= P.exposure_mul; y *= P.exposure_mul; z *= P.exposure_mul;
+        const float luma = x * RPF_F(0.2126) + y * RPF_F(0.7152) + z * RPF_F(0.0722);
+        const float shadow_mask = clamp01(1.0f - luma);
+        const float highlight_mask = clamp01(luma);
         const float shadow_gain = 1.0f + P.shadow * shadow_mask;
-        r *= shadow_gain; g *= shadow_gain; b *= shadow_gain;
+        x *= shadow_gain; y *= shadow_gain; z *= shadow_gain;
         const float highlight_gain = 1.0f + P.highlight * highlight_mask;
-        r *= highlight_gain; g *= highlight_gain; b *= highlight_gain;
+        x *= highlight_gain; y *= highlight_gain; z *= highlight_gain;
         if (P.flags & MF_BLACK) {
             const float t1 = 1.0f - highlight_mask;
             const float add = P.black * (t1 * t1);  // pow(1 - t, 2.0) correctly rounded
-            r += add; g += add; b += add;
+            x += add; y += add; z += add;
         }
         if (P.flags & MF_WHITE) {
             const float add = P.white * (highlight_mask * highlight_mask);
-            r += add; g += add; b += add;
+            x += add; y += add; z += add;
         }
         if (P.flags & MF_CONTRAST) {
-            r = (r - 0.5f) * P.contrast_c + 0.5f;
-            g = (g - 0.5f) * P.contrast_c + 0.5f;
-            b = (b - 0.5f) * P.contrast_c + 0.5f;
+            x = (x - 0.5f) * P.contrast_c + 0.5f;
+            y = (y - 0.5f) * P.contrast_c + 0.5f;
+            z = (z - 0.5f) * P.contrast_c + 0.5f;
         }
-        r = clampf(r, 0.0f, 1.0f); g = clampf(g, 0.0f, 1.0f); b = clampf(b, 0.0f, 1.0f);
+        x = clamp01(x); y = clamp01(y); z = clamp01(z);
         // brightness curve, wgsl:293-305
-        uint32_t ru = (uint32_t)(r * 65535.0f), gu = (uint32_t)(g * 65535.0f), bu = (uint32_t)(b * 65535.0f);
+        uint32_t xu = (uint32_t)(x * 65535.0f), yu = (uint32_t)(y * 65535.0f), zu = (uint32_t)(z * 65535.0f);
         if (!(P.flags & MF_BRIGHT_IDENTITY)) {
-            ru = luts.brightness(m, ru); gu = luts.brightness(m, gu); bu = luts.brightness(m, bu);
+            xu = luts.brightness(m, xu); yu = luts.brightness(m, yu); zu = luts.brightness(m, zu);
         }
-        r = div_u16_by(ru, 65535.0f, inv65535);
-        g = div_u16_by(gu, 65535.0f, inv65535);
-        b = div_u16_by(bu, 65535.0f, inv65535);
+        x = div_u16_by(xu, 65535.0f, inv65535);
+        y = div_u16_by(yu, 65535.0f, inv65535);
+        z = div_u16_by(zu, 65535.0f, inv65535);
+        const bool on = act ? act[n] : true;
+        r[n] = on ? x : r[n]; g[n] = on ? y : g[n]; b[n] = on ? z : b[n];
+    }
+}
+
+// wgsl main :279-336 on N pixels in lockstep (same operations per pixel, interleaved so that
+// constants are materialised once and the binary64 chains of different pixels overlap).
+// In place: r,g,b hold linear RGB on entry and the clamped display RGB on exit.
+template <int N, class Luts, class Tabs>
+RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],
+                       const MaskParams* mp, uint32_t num_masks, const Luts& luts, const Tabs& T)
+{
+    const float inv65535 = (float)(1.0 / 65535.0);
+    mask_rgb_stage<N>(mp[0], 0u, luts, r, g, b, nullptr);  // "main" is all ones (lib.rs:193-196)
+    for (uint32_t m = 1; m < num_masks; ++m) {
+        bool act[N];
+        for (int n = 0; n < N; ++n) act[n] = (active[n] >> m) & 1u;
+        mask_rgb_stage<N>(mp[m], m, luts, r, g, b, act);
     }
 
     // linear_srgb_to_oklch, wgsl:64-75
-    const float l = RPF_F(0.4122214708) * r + RPF_F(0.5363325363) * g + RPF_F(0.0514459929) * b;
-    const float mm = RPF_F(0.2119034982) * r + RPF_F(0.6806995451) * g + RPF_F(0.1073969566) * b;
-    const float s = RPF_F(0.0883024619) * r + RPF_F(0.2817188376) * g + RPF_F(0.6299787005) * b;
-    const float lc = powc<POW_CBRT>(l > 0.0f ? l : 0.0f, T.cbrt);
-    const float mc = powc<POW_CBRT>(mm > 0.0f ? mm : 0.0f, T.cbrt);
-    const float sc = powc<POW_CBRT>(s > 0.0f ? s : 0.0f, T.cbrt);
-    float L = RPF_F(0.2104542553) * lc + RPF_F(0.7936177850) * mc + RPF_F(-0.0040720468) * sc;
-    const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
-    const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;
-    float C = __builtin_sqrtf(A * A + Bq * Bq);
-    float h = div_by_const(atan2_cr(Bq, A), RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F));
-    if (h < 0.0f) h += 1.0f;
+    float L[N], C[N], h[N];
+    for (int n = 0; n < N; ++n) {
+        const float l = RPF_F(0.4122214708) * r[n] + RPF_F(0.5363325363) * g[n] + RPF_F(0.0514459929) * b[n];
+        const float mm = RPF_F(0.2119034982) * r[n] + RPF_F(0.6806995451) * g[n] + RPF_F(0.1073969566) * b[n];
+        const float s = RPF_F(0.0883024619) * r[n] + RPF_F(0.2817188376) * g[n] + RPF_F(0.6299787005) * b[n];
+        const float lc = powc<POW_CBRT>(l, T.cbrt);  // powc returns 0 for x <= 0 == pow(max(x, 0), 1/3)
+        const float mc = powc<POW_CBRT>(mm, T.cbrt);
+        const float sc = powc<POW_CBRT>(s, T.cbrt);
+        L[n] = RPF_F(0.2104542553) * lc + RPF_F(0.7936177850) * mc + RPF_F(-0.0040720468) * sc;
+        const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
+        const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;
+        C[n] = __builtin_sqrtf(A * A + Bq * Bq);
+        float hh = div_by_const(atan2_cr(Bq, A), RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F));
+        h[n] = hh < 0.0f ? hh + 1.0f : hh;
+    }
 
     // per-mask OKLCH curves, wgsl:312-331
-    uint32_t hue_k = 0;
+    uint32_t hue_k[N];
     for (uint32_t m = 0; m < num_masks; ++m) {
-        if (!((active >> m) & 1u)) continue;
         const MaskParams& P = mp[m];
-        const uint32_t hu = (uint32_t)(h * 65535.0f);
-        uint32_t nh = hu;
-        float sat_gain = P.sat_gain, light_gain = P.light_gain;
-        if ((P.flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) !=
-            (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST))
-            luts.hsl(m, hu, P, nh, sat_gain, light_gain);
-        hue_k = nh;
-        h = div_u16_by(nh, 65535.0f, inv65535);
-        C = C * sat_gain;
-        L = L * light_gain;
+        const bool trivial = (P.flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
+                             (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
+        for (int n = 0; n < N; ++n) {
+            const uint32_t hu = (uint32_t)(h[n] * 65535.0f);
+            uint32_t nh = hu;
+            float sat_gain = P.sat_gain, light_gain = P.light_gain;
+            if (!trivial) luts.hsl(m, hu, P, nh, sat_gain, light_gain);
+            const bool on = m == 0 ? true : (bool)((active[n] >> m) & 1u);
+            hue_k[n] = on ? nh : hue_k[n];
+            h[n] = on ? div_u16_by(nh, 65535.0f, inv65535) : h[n];
+            C[n] = on ? C[n] * sat_gain : C[n];
+            L[n] = on ? L[n] * light_gain : L[n];
+        }
     }
 
-    // oklch_to_linear_srgb, wgsl:77-84.  "main" (bit 0) is all ones by construction (lib.rs:193-196), so
-    // the hue reaching here is always k/65535 for the integer k the last active mask fetched.
-    float cs, sn;
-    sincos_hue(hue_k, T.sc, cs, sn);
-    const float oa = C * cs, ob = C * sn;
-    const float l_ = RPF_F(1.0) * L + RPF_F(0.3963377774) * oa + RPF_F(0.2158037573) * ob;
-    const float m_ = RPF_F(1.0) * L + RPF_F(-0.1055613458) * oa + RPF_F(-0.0638541728) * ob;
-    const float s_ = RPF_F(1.0) * L + RPF_F(-0.0894841775) * oa + RPF_F(-1.2914855480) * ob;
-    const float l3 = l_ * l_ * l_, m3 = m_ * m_ * m_, s3 = s_ * s_ * s_;
-    const float lr = RPF_F(4.0767416621) * l3 + RPF_F(-3.3077115913) * m3 + RPF_F(0.2309699292) * s3;
-    const float lg = RPF_F(-1.2684380046) * l3 + RPF_F(2.6097574011) * m3 + RPF_F(-0.3413193965) * s3;
-    const float lb = RPF_F(-0.0041960863) * l3 + RPF_F(-0.7034186147) * m3 + RPF_F(1.7076147010) * s3;
-
-    // linear_to_srgb + clamp, wgsl:95-103, 335-336
-    const float lin[3] = {lr, lg, lb};
-    float out[3];
-    for (int k = 0; k < 3; ++k) {
-        const float c = lin[k];
-        const float hi = RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - RPF_F(0.055);  // unused when c <= thr
-        const float v = c <= RPF_F(0.0031308) ? c * RPF_F(12.92) : hi;
-        out[k] = clampf(v, 0.0f, 1.0f);
+    // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336).  The hue reaching
+    // here is always k/65535 for the integer k the last active mask fetched ("main" is always active).
+    for (int n = 0; n < N; ++n) {
+        float cs, sn;
+        sincos_hue(hue_k[n], T.sc, cs, sn);
+        const float oa = C[n] * cs, ob = C[n] * sn;
+        const float l_ = RPF_F(1.0) * L[n] + RPF_F(0.3963377774) * oa + RPF_F(0.2158037573) * ob;
+        const float m_ = RPF_F(1.0) * L[n] + RPF_F(-0.1055613458) * oa + RPF_F(-0.0638541728) * ob;
+        const float s_ = RPF_F(1.0) * L[n] + RPF_F(-0.0894841775) * oa + RPF_F(-1.2914855480) * ob;
+        const float l3 = l_ * l_ * l_, m3 = m_ * m_ * m_, s3 = s_ * s_ * s_;
+        const float lin[3] = {RPF_F(4.0767416621) * l3 + RPF_F(-3.3077115913) * m3 + RPF_F(0.2309699292) * s3,
+                              RPF_F(-1.2684380046) * l3 + RPF_F(2.6097574011) * m3 + RPF_F(-0.3413193965) * s3,
+                              RPF_F(-0.0041960863) * l3 + RPF_F(-0.7034186147) * m3 + RPF_F(1.7076147010) * s3};
+        float out[3];
+        for (int k = 0; k < 3; ++k) {
+            const float c = lin[k];
+            const float hi = RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - RPF_F(0.055);  // unused when c <= thr
+            out[k] = clamp01(c <= RPF_F(0.0031308) ? c * RPF_F(12.92) : hi);
+        }
+        r[n] = out[0]; g[n] = out[1]; b[n] = out[2];
     }
-    o0 = out[0]; o1 = out[1]; o2 = out[2];
 }
 
 }  // namespace rpf

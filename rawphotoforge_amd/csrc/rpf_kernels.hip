@@ -1,23 +1,25 @@
 // rpf_kernels.hip — hand-written gfx950 (CDNA4) kernels of the RAW development hot path.
 //
-//   k_develop<MODE_DEMOSAIC>  u16 Bayer -> linear RGBA32F          (BASELINE config 2)
-//   k_develop<MODE_DEVELOP>   u16 Bayer -> display RGBA32F, fused  (BASELINE config 3: demosaic + WB +
+//   k_stream<MODE_DEMOSAIC>   u16 Bayer -> linear RGBA32F          (BASELINE config 2)
+//   k_stream<MODE_DEVELOP>    u16 Bayer -> display RGBA32F, fused  (BASELINE config 3: demosaic + WB +
 //                              camera matrix + the whole of wgsl main in ONE pass: 2 B in, 16 B out per pixel)
+//   k_tile<...>               the same two, LDS-tile front end (variant 1; the first design, kept for A/B)
 //   k_apply                   RGBA32F -> RGBA32F, wgsl main only   (what the reference's wgpu pass does)
 //
 // Replaces rust/photo-editor/src/wgpu_shader.wgsl:265-337 (kernel) and the dispatch half of
 // rust/photo-editor/src/gpu_image_processing.rs:214-400.  Not a translation of the WGSL
 // 16x16 one-thread-per-texel pass:
-//   * persistent workgroups (one per CU) walk 128-pixel-wide row tiles; a wavefront owns 64
-//     consecutive columns of TWO rows, so every store instruction writes 1 KiB contiguous;
-//   * the (TH+4) x 132 normalised CFA neighbourhood of the tile is staged once in LDS; each
-//     lane reads its 6-row column and gets the horizontal taps of the 5x5 stencil from its
-//     neighbours with DPP wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1);
-//   * the 65536-entry brightness curve (as u16, 128 KiB) and the transcendental tables
-//     (13 KiB) live in LDS for the lifetime of the workgroup, so curve gathers never
-//     leave the CU;
-//   * a vertical pixel pair always holds one R/B site and one G site, so both demosaic
-//     formula sets run without divergence.
+//   * k_stream: a wavefront owns a 60-column strip and walks down it two rows at a time.  Each lane keeps
+//     a rolling 6-row window of ITS column in registers (two coalesced 128-B row loads per step, every CFA
+//     sample normalised once), takes the horizontal taps of the 5x5 stencil from its neighbours with DPP
+//     wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) and carries the horizontal pair sums of a
+//     row down the window, so the stencil costs no LDS traffic and no barrier at all.  Lanes 0,1,62,63 are
+//     the strip's apron (64 loaded columns -> 60 outputs).
+//   * a vertical pixel pair always holds one R/B site and one G site, so both demosaic formula sets run
+//     without divergence, and the pair goes through the edit chain in lockstep (rpf_chain.h);
+//   * the transcendental tables (17 KiB) and, when it is not the identity, the 65536-entry brightness
+//     curve (u16, 128 KiB) are staged in LDS once per workgroup, so curve gathers never leave the CU;
+//   * every store is a global_store_dwordx4, 960 B contiguous per wave-instruction.
 // Pointwise/stencil path: HBM-bound by construction, no MFMA.
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -27,18 +29,6 @@
 namespace rpf {
 
 enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1 };
-
-constexpr int TILE_W = 128;          // two wavefronts side by side
-constexpr int PITCH = TILE_W + 4;    // 2-sample apron left and right
-
-struct DevelopArgs {
-    const uint16_t* cfa;   // row 0 = frame row y0 - 2
-    TileGeom g;
-    void* out;
-    RawParamsDev raw;
-    DeviceEdit ed;
-    uint32_t tiles_x, ntiles;
-};
 
 // ---------------------------------------------------------------------------
 // curve access (the Luts policy of edit_chain)
@@ -89,9 +79,9 @@ __device__ __forceinline__ void store_px(void* out, size_t pix, float r, float g
         o[0] = r; o[1] = g; o[2] = b;
     } else {  // image.rs:375-383: (v.clamp(0,1) * 255.0) as u8
         uint8_t* o = reinterpret_cast<uint8_t*>(out) + pix * 3;
-        o[0] = (uint8_t)(clampf(r, 0.0f, 1.0f) * 255.0f);
-        o[1] = (uint8_t)(clampf(g, 0.0f, 1.0f) * 255.0f);
-        o[2] = (uint8_t)(clampf(b, 0.0f, 1.0f) * 255.0f);
+        o[0] = (uint8_t)(clamp01(r) * 255.0f);
+        o[1] = (uint8_t)(clamp01(g) * 255.0f);
+        o[2] = (uint8_t)(clamp01(b) * 255.0f);
     }
 }
 
@@ -103,38 +93,217 @@ __device__ __forceinline__ uint32_t active_masks(const DeviceEdit& ed, size_t pi
     return active;
 }
 
-// ---------------------------------------------------------------------------
-// k_develop
-// ---------------------------------------------------------------------------
-template <int NT, int MODE, bool LDS_LUT, bool DPP, int OUTFMT>
-__global__ __launch_bounds__(NT) void k_develop(const DevelopArgs a)
+__device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T, uint16_t* lut, bool with_lut, int tid,
+                                             int nt)
 {
-    constexpr int PAIRS = NT / TILE_W;   // row pairs per tile
-    constexpr int TILE_H = 2 * PAIRS;
-    constexpr int TROWS = TILE_H + 4;
-    constexpr int TILE_ELEMS = TROWS * PITCH;
+    const uint4* src = reinterpret_cast<const uint4*>(ed.tabs);
+    uint4* dst = reinterpret_cast<uint4*>(T);
+    for (int i = tid; i < (int)(sizeof(MathTables) / 16); i += nt) dst[i] = src[i];
+    if (with_lut) {
+        const uint4* ls = reinterpret_cast<const uint4*>(ed.bright);
+        uint4* ld = reinterpret_cast<uint4*>(lut);
+        for (int i = tid; i < RPF_CURVE_RESOLUTION * 2 / 16; i += nt) ld[i] = ls[i];
+    }
+}
 
+// The vertical pixel pair at one column: demosaic both sites (one is R/B, the other G), camera matrix,
+// then — MODE_DEVELOP — vignette and the edit chain on the pair in lockstep, and the two stores.
+// c/s1/e1/d/v2/h2 [0] = top pixel, [1] = bottom pixel.  cx = RGGB cell column of this lane, cy_top of the top row.
+template <int MODE, bool LDS_LUT, int OUTFMT>
+__device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s1)[2], const float (&e1)[2],
+                                            const float (&d)[2], const float (&v2)[2], const float (&h2)[2], int cx,
+                                            int cy_top, const RawParamsDev& raw, const DeviceEdit& ed,
+                                            const DevLuts<LDS_LUT>& luts, const MathTables& T, int gx, int ry_top,
+                                            const TileGeom& g, bool col_live, void* out)
+{
+    const bool topA = cx == cy_top;  // top pixel is the R/B site, bottom the G site
+    const float cA = topA ? c[0] : c[1], s1A = topA ? s1[0] : s1[1], e1A = topA ? e1[0] : e1[1];
+    const float dA = topA ? d[0] : d[1], v2A = topA ? v2[0] : v2[1], h2A = topA ? h2[0] : h2[1];
+    const float cG = topA ? c[1] : c[0], s1G = topA ? s1[1] : s1[0], e1G = topA ? e1[1] : e1[0];
+    const float dG = topA ? d[1] : d[0], v2G = topA ? v2[1] : v2[0], h2G = topA ? h2[1] : h2[0];
+
+    const float cross = mhc_cross(cA, s1A, e1A, v2A, h2A);
+    const float diag = mhc_diag(cA, dA, v2A, h2A);
+    const float horiz = mhc_axis(cG, e1G, dG, h2G, v2G);
+    const float vert = mhc_axis(cG, s1G, dG, v2G, h2G);
+
+    // A site: cx == cy -> R site when cx == 0, B site when cx == 1; the G site's row parity is cx ^ 1
+    const float RA = cx == 0 ? cA : diag, GA = cross, BA = cx == 0 ? diag : cA;
+    const float RG = cx == 1 ? horiz : vert, GG = cG, BG = cx == 1 ? vert : horiz;
+
+    float r[2], gg[2], b[2];
+    cam_to_linear(raw.cam, topA ? RA : RG, topA ? GA : GG, topA ? BA : BG, r[0], gg[0], b[0]);
+    cam_to_linear(raw.cam, topA ? RG : RA, topA ? GG : GA, topA ? BG : BA, r[1], gg[1], b[1]);
+
+    const int W = (int)g.width, rows = (int)g.rows;
+    bool live[2];
+    size_t pix[2];
+    for (int k = 0; k < 2; ++k) {
+        live[k] = col_live && ry_top + k < rows;
+        pix[k] = live[k] ? (size_t)(ry_top + k) * W + gx : 0;
+    }
+    if (MODE == MODE_DEVELOP) {
+        if (ed.vign_strength != 0.0f) {  // wgsl:166-178, global coordinates
+            for (int k = 0; k < 2; ++k) {
+                const float gain = vignette_gain(ed.vign_strength, gx, (int)g.y0 + ry_top + k, (float)W, (float)g.height);
+                r[k] *= gain; gg[k] *= gain; b[k] *= gain;
+            }
+        }
+        uint32_t active[2] = {1u, 1u};
+        if (ed.num_masks > 1)
+            for (int k = 0; k < 2; ++k) active[k] = active_masks(ed, pix[k], (size_t)rows * W);
+        edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
+    }
+    for (int k = 0; k < 2; ++k)
+        if (live[k]) store_px<OUTFMT>(out, pix[k], r[k], gg[k], b[k]);
+}
+
+// ---------------------------------------------------------------------------
+// k_stream — rolling-window front end
+// ---------------------------------------------------------------------------
+constexpr int STRIP_W = 60;  // output columns per wavefront (lanes 2..61)
+
+struct StreamArgs {
+    const uint16_t* cfa;   // row 0 = frame row y0 - 2
+    TileGeom g;
+    void* out;
+    RawParamsDev raw;
+    DeviceEdit ed;
+    uint32_t strips, seg_pairs, nitems;
+};
+
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+__global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    MathTables* T = reinterpret_cast<MathTables*>(smem);
+    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
+    const int tid = threadIdx.x;
+    if (MODE == MODE_DEVELOP) {
+        stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+        __syncthreads();  // the only barrier of the kernel
+    }
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl};
+
+    const int lane = tid & 63;
+    const int W = (int)a.g.width, H = (int)a.g.height;
+    const int y0 = (int)a.g.y0, rows = (int)a.g.rows;
+    const int total_pairs = (rows + 1) / 2;
+    const int bp = (y0 + a.raw.yo) & 1;  // RGGB cell row of window positions 0, 2, 4
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + (tid >> 6));
+    const uint32_t nwaves = gridDim.x * (NT / 64);
+
+    // Work distribution: with a ticket counter every wavefront draws the next strip segment (a queue that
+    // drains: each draw is >= the previous, the loop ends at the first draw >= nitems); without one the
+    // items are dealt round-robin.  Either way the loop bound is wave-uniform.
+    uint32_t* const ticket = MODE == MODE_DEVELOP ? a.ed.ticket : nullptr;
+    auto next_item = [&](uint32_t prev) -> uint32_t {
+        if (!ticket) return prev + nwaves;
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(ticket, 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    for (uint32_t item = ticket ? next_item(0) : wave; item < a.nitems; item = next_item(item)) {
+        const uint32_t seg = item / a.strips, strip = item - seg * a.strips;
+        const int x0 = (int)strip * STRIP_W;
+        const int pair0 = (int)(seg * a.seg_pairs);
+        const int npairs = min((int)a.seg_pairs, total_pairs - pair0);
+        const int xl = x0 - 2 + lane;  // this lane's column (lanes 0,1,62,63: apron)
+        int gx = reflect101(xl, W);
+        gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);  // columns past a ragged strip: unused
+        const int cx = (gx + a.raw.xo) & 1;
+        // normalisation constants of this lane's column for even / odd window positions
+        const int cyE = bp, cyO = bp ^ 1;
+        const float blkE = cyE ? (cx ? a.raw.black[3] : a.raw.black[2]) : (cx ? a.raw.black[1] : a.raw.black[0]);
+        const float rngE = cyE ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
+        const float sclE = cyE ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
+        const float blkO = cyO ? (cx ? a.raw.black[3] : a.raw.black[2]) : (cx ? a.raw.black[1] : a.raw.black[0]);
+        const float rngO = cyO ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
+        const float sclO = cyO ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
+
+        // band-relative row ry (any integer) -> raw sample of this lane's column
+        auto load_row = [&](int ry) -> uint32_t {
+            int gy = reflect101(y0 + ry, H);
+            int br = gy - (y0 - 2);
+            br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);  // rows past a ragged band: unused
+            return a.cfa[(size_t)br * W + gx];
+        };
+        auto normE = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkE, 0.0f), rngE) * sclE; };
+        auto normO = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkO, 0.0f), rngO) * sclO; };
+
+        // window position i <-> band row 2*pair - 2 + i.  v: samples, p1/p2: W+E sums at distance 1 / 2.
+        const int rbase = 2 * pair0 - 2;
+        float v0 = normE(load_row(rbase + 0)), v1 = normO(load_row(rbase + 1));
+        float v2 = normE(load_row(rbase + 2)), v3 = normO(load_row(rbase + 3));
+        uint32_t n4 = load_row(rbase + 4), n5 = load_row(rbase + 5);
+        float l, r, p1_1, p1_2, p1_3, p2_2, p2_3;
+        l = from_left(v1, v1); r = from_right(v1, v1); p1_1 = l + r;
+        l = from_left(v2, v2); r = from_right(v2, v2); p1_2 = l + r;
+        p2_2 = from_left(l, l) + from_right(r, r);
+        l = from_left(v3, v3); r = from_right(v3, v3); p1_3 = l + r;
+        p2_3 = from_left(l, l) + from_right(r, r);
+
+        const bool col_live = lane >= 2 && lane < 2 + STRIP_W && xl < W;
+        for (int p = 0; p < npairs; ++p) {  // wave-uniform
+            const float v4 = normE(n4), v5 = normO(n5);
+            if (p + 1 < npairs) {  // prefetch the next step's two rows
+                n4 = load_row(rbase + 2 * p + 6);
+                n5 = load_row(rbase + 2 * p + 7);
+            }
+            l = from_left(v4, v4); r = from_right(v4, v4);
+            const float p1_4 = l + r;
+            const float p2_4 = from_left(l, l) + from_right(r, r);
+            l = from_left(v5, v5); r = from_right(v5, v5);
+            const float p1_5 = l + r;
+            const float p2_5 = from_left(l, l) + from_right(r, r);
+
+            // neighbourhood sums: top pixel = window position 2, bottom = 3
+            const float c[2] = {v2, v3};
+            const float s1[2] = {v1 + v3, v2 + v4};
+            const float e1[2] = {p1_2, p1_3};
+            const float d[2] = {p1_1 + p1_3, p1_2 + p1_4};
+            const float vv[2] = {v0 + v4, v1 + v5};
+            const float h2[2] = {p2_2, p2_3};
+            finish_pair<MODE, LDS_LUT, OUTFMT>(c, s1, e1, d, vv, h2, cx, bp, a.raw, a.ed, luts, *T, xl, 2 * (pair0 + p), a.g,
+                                               col_live, a.out);
+            // slide the window down two rows
+            v0 = v2; v1 = v3; v2 = v4; v3 = v5;
+            p1_1 = p1_3; p1_2 = p1_4; p1_3 = p1_5;
+            p2_2 = p2_4; p2_3 = p2_5;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_tile — LDS-tile front end (variant 1): persistent workgroups walk 128 x TILE_H tiles; the
+// (TILE_H+4) x 132 normalised CFA neighbourhood is staged in LDS, lanes read their 6-row column and
+// take the horizontal taps by DPP (lanes 0/63 patch the two samples beyond the wavefront from LDS).
+// ---------------------------------------------------------------------------
+constexpr int TILE_W = 128;
+constexpr int PITCH = TILE_W + 4;
+
+struct TileArgs {
+    const uint16_t* cfa;
+    TileGeom g;
+    void* out;
+    RawParamsDev raw;
+    DeviceEdit ed;
+    uint32_t tiles_x, ntiles;
+};
+
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+__global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
+{
+    constexpr int TILE_H = 2 * (NT / TILE_W);
+    constexpr int TILE_ELEMS = (TILE_H + 4) * PITCH;
     extern __shared__ __align__(16) unsigned char smem[];
     float* tile = reinterpret_cast<float*>(smem);
     MathTables* T = reinterpret_cast<MathTables*>(smem + ((TILE_ELEMS * 4 + 15) & ~15));
     uint16_t* lut = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(T) + sizeof(MathTables));
-
     const int tid = threadIdx.x;
     const int W = (int)a.g.width, H = (int)a.g.height;
     const int y0 = (int)a.g.y0, rows = (int)a.g.rows;
-
-    if (MODE == MODE_DEVELOP) {
-        // stage the transcendental tables (and mask 0's brightness curve) once per workgroup
-        const uint4* src = reinterpret_cast<const uint4*>(a.ed.tabs);
-        uint4* dst = reinterpret_cast<uint4*>(T);
-        for (int i = tid; i < (int)(sizeof(MathTables) / 16); i += NT) dst[i] = src[i];
-        if (LDS_LUT) {
-            const uint4* ls = reinterpret_cast<const uint4*>(a.ed.bright);
-            uint4* ld = reinterpret_cast<uint4*>(lut);
-            for (int i = tid; i < RPF_CURVE_RESOLUTION * 2 / 16; i += NT) ld[i] = ls[i];
-        }
-    }
-
+    if (MODE == MODE_DEVELOP) stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     const int lx = tid & (TILE_W - 1);
     const int ly = 2 * (tid / TILE_W);
     const int lane = tid & 63;
@@ -142,102 +311,45 @@ __global__ __launch_bounds__(NT) void k_develop(const DevelopArgs a)
 
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         const int tx0 = (int)(t % a.tiles_x) * TILE_W;
-        const int ty0 = (int)(t / a.tiles_x) * TILE_H;  // tile-relative row of the band
-
+        const int ty0 = (int)(t / a.tiles_x) * TILE_H;
         __syncthreads();  // previous tile fully consumed (and tables staged)
         for (int i = tid; i < TILE_ELEMS; i += NT) {
             const int r = i / PITCH, c = i - r * PITCH;
             int gx = reflect101(tx0 - 2 + c, W);
-            gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);          // columns past a ragged tile: unused
+            gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
             int gy = reflect101(y0 + ty0 - 2 + r, H);
-            int br = gy - (y0 - 2);                                // row of the band buffer
-            br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);     // rows past a ragged tile: unused
+            int br = gy - (y0 - 2);
+            br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);
             const uint32_t raw = a.cfa[(size_t)br * W + gx];
             const int cell = ((gx + a.raw.xo) & 1) + 2 * ((gy + a.raw.yo) & 1);
             tile[i] = cfa_normalise(raw, cell, a.raw);
         }
         __syncthreads();
-
-        // 6-row column of this lane: tile rows ly .. ly+5 <-> frame rows (top - 2) .. (top + 3)
         const float* col = tile + ly * PITCH + lx + 2;
         float v[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = col[i * PITCH];
-
-        float p1[6], p2[6];  // p1[i] = W + E at distance 1 on tile row ly+i, p2 at distance 2
-        if (DPP) {
-            // lanes 0 / 63 fetch the two samples beyond the wavefront's 64 columns, per row
-            const int hoff = lane == 0 ? -2 : (lane == 63 ? 1 : -(lx & 1));
+        float p1[6], p2[6];
+        const int hoff = lane == 0 ? -2 : (lane == 63 ? 1 : -(lx & 1));
 #pragma unroll
-            for (int i = 1; i <= 4; ++i) {
-                const float2 hv = *reinterpret_cast<const float2*>(col + i * PITCH + hoff);
-                const float l1 = from_left(v[i], hv.y);    // x-1 (lane 0: column -1 of the wavefront)
-                const float r1 = from_right(v[i], hv.x);   // x+1 (lane 63: column 64)
-                p1[i] = l1 + r1;
-                if (i == 2 || i == 3) {
-                    const float l2 = from_left(l1, hv.x);   // x-2
-                    const float r2 = from_right(r1, hv.y);  // x+2
-                    p2[i] = l2 + r2;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 1; i <= 4; ++i) {
-                p1[i] = col[i * PITCH - 1] + col[i * PITCH + 1];
-                if (i == 2 || i == 3) p2[i] = col[i * PITCH - 2] + col[i * PITCH + 2];
-            }
+        for (int i = 1; i <= 4; ++i) {
+            const float2 hv = *reinterpret_cast<const float2*>(col + i * PITCH + hoff);
+            const float l1 = from_left(v[i], hv.y);   // x-1 (lane 0: column -1 of the wavefront)
+            const float r1 = from_right(v[i], hv.x);  // x+1 (lane 63: column 64)
+            p1[i] = l1 + r1;
+            if (i == 2 || i == 3) p2[i] = from_left(l1, hv.x) + from_right(r1, hv.y);
         }
-
         const int gx = tx0 + lx;
-        const int ry_top = ty0 + ly;               // band-relative row of the top pixel
-        const int gy_top = y0 + ry_top;
         const int cx = (gx + a.raw.xo) & 1;
-        const int cy_top = (gy_top + a.raw.yo) & 1;
-        const bool topA = cx == cy_top;            // top pixel is the R/B site, bottom the G site
-
-        // neighbourhood sums: top pixel = tile row ly+2, bottom = ly+3
-        const float c_t = v[2], s1_t = v[1] + v[3], e1_t = p1[2], d_t = p1[1] + p1[3], v2_t = v[0] + v[4], h2_t = p2[2];
-        const float c_b = v[3], s1_b = v[2] + v[4], e1_b = p1[3], d_b = p1[2] + p1[4], v2_b = v[1] + v[5], h2_b = p2[3];
-
-        const float cA = topA ? c_t : c_b, s1A = topA ? s1_t : s1_b, e1A = topA ? e1_t : e1_b;
-        const float dA = topA ? d_t : d_b, v2A = topA ? v2_t : v2_b, h2A = topA ? h2_t : h2_b;
-        const float cG = topA ? c_b : c_t, s1G = topA ? s1_b : s1_t, e1G = topA ? e1_b : e1_t;
-        const float dG = topA ? d_b : d_t, v2G = topA ? v2_b : v2_t, h2G = topA ? h2_b : h2_t;
-
-        const float cross = mhc_cross(cA, s1A, e1A, v2A, h2A);
-        const float diag = mhc_diag(cA, dA, v2A, h2A);
-        const float horiz = mhc_axis(cG, e1G, dG, h2G, v2G);
-        const float vert = mhc_axis(cG, s1G, dG, v2G, h2G);
-
-        // A site: cx == cy -> R site when cx == 0, B site when cx == 1
-        const float RA = cx == 0 ? cA : diag, GA = cross, BA = cx == 0 ? diag : cA;
-        // G site: its row parity is the opposite of the A site's (which is cx)
-        const int cyG = cx ^ 1;
-        const float RG = cyG == 0 ? horiz : vert, GG = cG, BG = cyG == 0 ? vert : horiz;
-
-        float px[2][3];
-        cam_to_linear(a.raw.cam, topA ? RA : RG, topA ? GA : GG, topA ? BA : BG, px[0][0], px[0][1], px[0][2]);
-        cam_to_linear(a.raw.cam, topA ? RG : RA, topA ? GG : GA, topA ? BG : BA, px[1][0], px[1][1], px[1][2]);
-
-        const bool in_x = gx < W;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int ry = ry_top + k;
-            const bool live = in_x && ry < rows;
-            const size_t pix = (size_t)(live ? ry : 0) * W + (live ? gx : 0);
-            float r = px[k][0], g = px[k][1], b = px[k][2];
-            if (MODE == MODE_DEVELOP) {
-                if (a.ed.vign_strength != 0.0f) {  // wgsl:166-178, global coordinates
-                    const float gain = vignette_gain(a.ed.vign_strength, gx, y0 + ry, (float)W, (float)H);
-                    r *= gain; g *= gain; b *= gain;
-                }
-                const uint32_t active = active_masks(a.ed, pix, (size_t)rows * W);
-                float o0, o1, o2;
-                edit_chain(r, g, b, active, a.ed.mp, a.ed.num_masks, luts, *T, o0, o1, o2);
-                r = o0; g = o1; b = o2;
-            }
-            if (live) store_px<OUTFMT>(a.out, pix, r, g, b);
-        }
+        const int cy_top = (y0 + ty0 + ly + a.raw.yo) & 1;
+        const float c[2] = {v[2], v[3]};
+        const float s1[2] = {v[1] + v[3], v[2] + v[4]};
+        const float e1[2] = {p1[2], p1[3]};
+        const float d[2] = {p1[1] + p1[3], p1[2] + p1[4]};
+        const float vv[2] = {v[0] + v[4], v[1] + v[5]};
+        const float h2[2] = {p2[2], p2[3]};
+        finish_pair<MODE, LDS_LUT, OUTFMT>(c, s1, e1, d, vv, h2, cx, cy_top, a.raw, a.ed, luts, *T, gx, ty0 + ly, a.g,
+                                           gx < W, a.out);
     }
 }
 
@@ -267,44 +379,40 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     MathTables* T = reinterpret_cast<MathTables*>(smem);
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
     const int tid = threadIdx.x;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(a.ed.tabs);
-        uint4* dst = reinterpret_cast<uint4*>(T);
-        for (int i = tid; i < (int)(sizeof(MathTables) / 16); i += NT) dst[i] = src[i];
-        if (LDS_LUT) {
-            const uint4* ls = reinterpret_cast<const uint4*>(a.ed.bright);
-            uint4* ld = reinterpret_cast<uint4*>(lut);
-            for (int i = tid; i < RPF_CURVE_RESOLUTION * 2 / 16; i += NT) ld[i] = ls[i];
-        }
-    }
+    stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl};
     const int W = (int)a.g.width, H = (int)a.g.height;
     const size_t npix = (size_t)a.g.rows * W;
     const size_t stride = (size_t)gridDim.x * NT * 2;
     for (size_t base = (size_t)blockIdx.x * NT * 2; base < npix; base += stride) {
+        float r[2], g[2], b[2];
+        uint32_t active[2];
+        size_t pix[2];
+        bool live[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const size_t pix = base + (size_t)k * NT + tid;
-            if (pix >= npix) continue;
-            const int ry = (int)(pix / W), x = (int)(pix - (size_t)ry * W);
+            const size_t p = base + (size_t)k * NT + tid;
+            live[k] = p < npix;
+            pix[k] = live[k] ? p : npix - 1;
+            const int ry = (int)(pix[k] / W), x = (int)(pix[k] - (size_t)ry * W);
             const int gy = (int)a.g.y0 + ry;
-            float r, g, b;
             if (LENS) {  // wgsl:123-163; a.in is the whole frame
-                lens_sample(TexFetch{a.in, W}, W, H, x, gy, a.ed.lens_strength, r, g, b);
+                lens_sample(TexFetch{a.in, W}, W, H, x, gy, a.ed.lens_strength, r[k], g[k], b[k]);
             } else {
-                const float4 v = a.in[pix];
-                r = v.x; g = v.y; b = v.z;
+                const float4 v = a.in[pix[k]];
+                r[k] = v.x; g[k] = v.y; b[k] = v.z;
             }
             if (a.ed.vign_strength != 0.0f) {
                 const float gain = vignette_gain(a.ed.vign_strength, x, gy, (float)W, (float)H);
-                r *= gain; g *= gain; b *= gain;
+                r[k] *= gain; g[k] *= gain; b[k] *= gain;
             }
-            const uint32_t active = active_masks(a.ed, pix, npix);
-            float o0, o1, o2;
-            edit_chain(r, g, b, active, a.ed.mp, a.ed.num_masks, luts, *T, o0, o1, o2);
-            store_px<OUTFMT>(a.out, pix, o0, o1, o2);
+            active[k] = a.ed.num_masks > 1 ? active_masks(a.ed, pix[k], npix) : 1u;
         }
+        edit_chain<2>(r, g, b, active, a.ed.mp, a.ed.num_masks, luts, *T);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (live[k]) store_px<OUTFMT>(a.out, pix[k], r[k], g[k], b[k]);
     }
 }
 
@@ -329,13 +437,6 @@ __global__ __launch_bounds__(256) void k_pad_rgb(const float* in, size_t npix, f
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-template <int NT>
-constexpr size_t develop_lds(bool develop, bool lds_lut)
-{
-    return (size_t)((((2 * (NT / TILE_W) + 4) * PITCH * 4) + 15) & ~15) + (develop ? sizeof(MathTables) : 0) +
-           (lds_lut ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0);
-}
-
 template <class K>
 static hipError_t set_lds(K kernel, size_t bytes)
 {
@@ -344,28 +445,10 @@ static hipError_t set_lds(K kernel, size_t bytes)
                                (int)bytes);
 }
 
-template <int NT, int MODE, bool LDS_LUT, bool DPP, int OUTFMT>
-static hipError_t run_develop(const LaunchCfg& cfg, DevelopArgs& a, int blocks_per_cu, hipStream_t s)
-{
-    constexpr int TILE_H = 2 * (NT / TILE_W);
-    a.tiles_x = (a.g.width + TILE_W - 1) / TILE_W;
-    const uint32_t tiles_y = (a.g.rows + TILE_H - 1) / TILE_H;
-    a.ntiles = a.tiles_x * tiles_y;
-    if (a.ntiles == 0) return hipSuccess;
-    const size_t lds = develop_lds<NT>(MODE == MODE_DEVELOP, LDS_LUT);
-    auto kernel = k_develop<NT, MODE, LDS_LUT, DPP, OUTFMT>;
-    hipError_t e = set_lds(kernel, lds);
-    if (e != hipSuccess) return e;
-    uint32_t grid = (uint32_t)cfg.num_cus * (uint32_t)blocks_per_cu;
-    if (grid > a.ntiles) grid = a.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
-    return hipGetLastError();
-}
-
 static bool needs_lds_lut(const DeviceEdit& ed) { return !(ed.mp[0].flags & MF_BRIGHT_IDENTITY); }
 
 // Operand checks shared by the launchers: a tile must be non-empty, inside its frame and large
-// enough for the reflect-101 border; a 128-KiB LDS curve needs one workgroup per CU.
+// enough for the reflect-101 border.
 static hipError_t check_geom(const TileGeom& g, bool bayer)
 {
     if (g.width == 0 || g.height == 0 || g.rows == 0) return hipErrorInvalidValue;
@@ -375,50 +458,105 @@ static hipError_t check_geom(const TileGeom& g, bool bayer)
     return hipSuccess;
 }
 
+static hipError_t check_edit(const DeviceEdit& ed)
+{
+    if (!ed.tabs || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS) return hipErrorInvalidValue;
+    if (ed.num_masks > 1 && !ed.mask_planes) return hipErrorInvalidValue;
+    return hipSuccess;
+}
+
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
+                             const DeviceEdit* ed, void* d_out, hipStream_t s)
+{
+    StreamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
+    if (ed) a.ed = *ed;
+    const uint32_t total_pairs = (g.rows + 1) / 2;
+    a.strips = (g.width + STRIP_W - 1) / STRIP_W;
+    // rows per wave-item: 8 pairs amortise the 4-row window prologue (20 row loads per 16 rows)
+    a.seg_pairs = MODE == MODE_DEVELOP ? 4 : 8;
+    const uint32_t segs = (total_pairs + a.seg_pairs - 1) / a.seg_pairs;
+    a.nitems = a.strips * segs;
+    const size_t lds = MODE == MODE_DEVELOP ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
+    auto kernel = k_stream<NT, MODE, LDS_LUT, OUTFMT>;
+    hipError_t e = set_lds(kernel, lds);
+    if (e != hipSuccess) return e;
+    constexpr uint32_t WPB = NT / 64;
+    uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
+    if (MODE == MODE_DEVELOP) {
+        // persistent workgroups (LDS tables staged once) fed by the ticket queue: as many as are resident
+        const uint32_t cap = (uint32_t)cfg.num_cus * (LDS_LUT ? 1u : (uint32_t)(1024 / NT));
+        if (grid > cap) grid = cap;
+        if (a.ed.ticket) {
+            e = hipMemsetAsync(a.ed.ticket, 0, sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+static hipError_t run_tile(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
+                           const DeviceEdit* ed, void* d_out, int blocks_per_cu, hipStream_t s)
+{
+    constexpr int TILE_H = 2 * (NT / TILE_W);
+    TileArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
+    if (ed) a.ed = *ed;
+    a.tiles_x = (g.width + TILE_W - 1) / TILE_W;
+    a.ntiles = a.tiles_x * ((g.rows + TILE_H - 1) / TILE_H);
+    const size_t lds = (size_t)((((TILE_H + 4) * PITCH * 4) + 15) & ~15) +
+                       (MODE == MODE_DEVELOP ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0);
+    auto kernel = k_tile<NT, MODE, LDS_LUT, OUTFMT>;
+    hipError_t e = set_lds(kernel, lds);
+    if (e != hipSuccess) return e;
+    uint32_t grid = (uint32_t)cfg.num_cus * (uint32_t)blocks_per_cu;
+    if (grid > a.ntiles) grid = a.ntiles;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                            float* d_rgba, hipStream_t s)
 {
     hipError_t e = check_geom(g, true);
     if (e != hipSuccess) return e;
     if (!d_cfa || !d_rgba) return hipErrorInvalidValue;
-    DevelopArgs a;
-    memset(&a, 0, sizeof(a));
-    a.cfa = d_cfa; a.g = g; a.out = d_rgba; a.raw = raw;
-    if (cfg.variant == 1) return run_develop<512, MODE_DEMOSAIC, false, false, OUT_RGBA_F32>(cfg, a, 4, s);
-    return run_develop<512, MODE_DEMOSAIC, false, true, OUT_RGBA_F32>(cfg, a, 4, s);
+    if (cfg.variant == 1) return run_tile<512, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, 4, s);
+    return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s);
 }
 
 template <int OUTFMT>
-static hipError_t develop_fmt(const LaunchCfg& cfg, DevelopArgs& a, hipStream_t s)
+static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
+                              const DeviceEdit& ed, void* d_out, hipStream_t s)
 {
-    const bool lut = needs_lds_lut(a.ed);
-    // variant 1: no DPP (every stencil tap from LDS); variant 2: 1024-thread workgroups
-    if (cfg.variant == 1)
-        return lut ? run_develop<512, MODE_DEVELOP, true, false, OUTFMT>(cfg, a, 1, s)
-                   : run_develop<512, MODE_DEVELOP, false, false, OUTFMT>(cfg, a, 2, s);
-    if (cfg.variant == 2)
-        return lut ? run_develop<1024, MODE_DEVELOP, true, true, OUTFMT>(cfg, a, 1, s)
-                   : run_develop<1024, MODE_DEVELOP, false, true, OUTFMT>(cfg, a, 1, s);
-    return lut ? run_develop<512, MODE_DEVELOP, true, true, OUTFMT>(cfg, a, 1, s)
-               : run_develop<512, MODE_DEVELOP, false, true, OUTFMT>(cfg, a, 2, s);
+    const bool lut = needs_lds_lut(ed);
+    if (cfg.variant == 1)  // LDS-tile front end
+        return lut ? run_tile<512, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, 1, s)
+                   : run_tile<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, 2, s);
+    if (cfg.variant == 2)  // streaming, 512-thread workgroups
+        return lut ? run_stream<512, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
+                   : run_stream<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
+               : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
 }
 
 hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                           const DeviceEdit& ed, void* d_out, int out_format, hipStream_t s)
 {
     hipError_t e = check_geom(g, true);
+    if (e == hipSuccess) e = check_edit(ed);
     if (e != hipSuccess) return e;
-    if (!d_cfa || !d_out || !ed.tabs || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS)
-        return hipErrorInvalidValue;
-    if (ed.num_masks > 1 && !ed.mask_planes) return hipErrorInvalidValue;
+    if (!d_cfa || !d_out) return hipErrorInvalidValue;
     if (ed.lens_strength != 0.0f) return hipErrorInvalidValue;  // needs the resampling pass (launch_apply)
-    DevelopArgs a;
-    memset(&a, 0, sizeof(a));
-    a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw; a.ed = ed;
     switch (out_format) {
-    case OUT_RGBA_F32: return develop_fmt<OUT_RGBA_F32>(cfg, a, s);
-    case OUT_RGB_F32: return develop_fmt<OUT_RGB_F32>(cfg, a, s);
-    case OUT_RGB_U8: return develop_fmt<OUT_RGB_U8>(cfg, a, s);
+    case OUT_RGBA_F32: return develop_fmt<OUT_RGBA_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
+    case OUT_RGB_F32: return develop_fmt<OUT_RGB_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
+    case OUT_RGB_U8: return develop_fmt<OUT_RGB_U8>(cfg, d_cfa, raw, g, ed, d_out, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -426,13 +564,13 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
 template <bool LDS_LUT, bool LENS, int OUTFMT>
 static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
 {
-    constexpr int NT = 512;
+    constexpr int NT = LDS_LUT ? 1024 : 256;
     const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0);
     auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     const size_t npix = (size_t)a.g.rows * a.g.width;
-    size_t grid = (size_t)cfg.num_cus * (LDS_LUT ? 1 : 2);
+    size_t grid = (size_t)cfg.num_cus * (LDS_LUT ? 1 : 8);
     const size_t need = (npix + NT * 2 - 1) / (NT * 2);
     if (grid > need) grid = need;
     hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(NT), lds, s, a);
@@ -452,10 +590,9 @@ hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom&
                         int out_format, hipStream_t s)
 {
     hipError_t e = check_geom(g, false);
+    if (e == hipSuccess) e = check_edit(ed);
     if (e != hipSuccess) return e;
-    if (!d_in || !d_out || !ed.tabs || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS)
-        return hipErrorInvalidValue;
-    if (ed.num_masks > 1 && !ed.mask_planes) return hipErrorInvalidValue;
+    if (!d_in || !d_out) return hipErrorInvalidValue;
     // the resampling branch reads anywhere in the frame: the tile must be the whole frame
     if (ed.lens_strength != 0.0f && (g.y0 != 0 || g.rows != g.height)) return hipErrorInvalidValue;
     if (ed.lens_strength != 0.0f && d_in == d_out) return hipErrorInvalidValue;

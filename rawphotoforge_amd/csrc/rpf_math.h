@@ -102,7 +102,7 @@ RPF_HD float div_by_const(float x, float d, float rd)
 // Correctly rounded x^c for x >= 0 (c fixed by KIND).  Exhaustively equal to the oracle's
 // cr_powf on [2^-21, 1.25) for cbrt and [2^-9, 2^3) for gamma; same algorithm (rel. error
 // < 2^-50 before the single rounding) on the rest of the binary32 range.
-// x = 0 -> 0, x = +inf -> +inf, NaN -> NaN; x < 0 is the caller's business (unspecified).
+// x <= 0 -> 0 (so pow(max(x, 0), c) needs no separate max); inputs must be finite.
 template <int KIND, class TabT>
 RPF_HD float powc(float x, const TabT& T)
 {
@@ -124,7 +124,7 @@ RPF_HD float powc(float x, const TabT& T)
     p = __builtin_fma(t, p, K::c1);
     p = __builtin_fma(t, p, 1.0);
     const float y = (float)((T.E[ei] * tj) * p);
-    return ebits == 0x7ffu ? x : (x > 0.0f ? y : 0.0f);
+    return x > 0.0f ? y : 0.0f;  // finite inputs only (inf/NaN in -> unspecified out)
 }
 
 // atan(q) = q + q^3 P(q^2), |q| <= tan(pi/8); rel. error 2^-52.7 (tools/gen_math_consts.py)

@@ -75,9 +75,10 @@ void twin_edit_chain(const float* rgb, size_t npix, const rpf::MaskParams* mp, u
     const uint32_t active = num_masks >= 32 ? 0xffffffffu : ((1u << num_masks) - 1u);
 #pragma omp parallel for
     for (long long i = 0; i < (long long)npix; ++i) {
-        float o0, o1, o2;
-        rpf::edit_chain(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], active, mp, num_masks, L, T, o0, o1, o2);
-        rgba_out[i * 4] = o0; rgba_out[i * 4 + 1] = o1; rgba_out[i * 4 + 2] = o2; rgba_out[i * 4 + 3] = 1.0f;
+        float r[1] = {rgb[i * 3]}, g[1] = {rgb[i * 3 + 1]}, b[1] = {rgb[i * 3 + 2]};
+        const uint32_t act[1] = {active};
+        rpf::edit_chain<1>(r, g, b, act, mp, num_masks, L, T);
+        rgba_out[i * 4] = r[0]; rgba_out[i * 4 + 1] = g[0]; rgba_out[i * 4 + 2] = b[0]; rgba_out[i * 4 + 3] = 1.0f;
     }
 }
 
