@@ -68,7 +68,6 @@ struct rpf_editor {
     uint16_t* d_bright = nullptr;
     ushort4* d_hsl = nullptr;
     uint8_t* d_masks = nullptr;
-    uint32_t* d_ticket = nullptr;  // work-queue counter of the fused kernel
     uint32_t lut_capacity = 0;    // masks worth of LUT storage
     uint32_t mask_capacity = 0;   // user-mask planes allocated
     uint64_t uploaded_params = 0, uploaded_masks = 0;
@@ -259,8 +258,6 @@ static int editor_device_init(rpf_editor* e, rpf_processor* p)
     e->proc = p;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void**)&e->d_ticket, sizeof(uint32_t)));
-    e->dev.ticket = e->d_ticket;
     p->editors.fetch_add(1);
     return ok();
 }
@@ -270,8 +267,7 @@ void rpf_editor_destroy(rpf_editor* e)
     if (!e) return;
     if (e->proc && hipSetDevice(e->proc->device) == hipSuccess) {
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks,
-                        e->d_ticket};
+        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -29,6 +29,7 @@
 namespace rpf {
 
 enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1 };
+enum { OUT_RGBA_F32_PLAIN = 3 };  // internal (A/B only): RGBA32F with ordinary stores
 
 // ---------------------------------------------------------------------------
 // curve access (the Luts policy of edit_chain)
@@ -73,6 +74,11 @@ template <int OUTFMT>
 __device__ __forceinline__ void store_px(void* out, size_t pix, float r, float g, float b)
 {
     if (OUTFMT == OUT_RGBA_F32) {
+        // nontemporal: the frame is written once and never re-read by the kernel; measured on MI355X the
+        // demosaic kernel goes from 4.2 to 5.7 TB/s with it (profiles/r01_experiments.md)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4f{r, g, b, 1.0f}, reinterpret_cast<v4f*>(out) + pix);
+    } else if (OUTFMT == OUT_RGBA_F32_PLAIN) {
         reinterpret_cast<float4*>(out)[pix] = make_float4(r, g, b, 1.0f);
     } else if (OUTFMT == OUT_RGB_F32) {  // image.rs:202-277
         float* o = reinterpret_cast<float*>(out) + pix * 3;
@@ -161,7 +167,7 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
 // ---------------------------------------------------------------------------
 // k_stream — rolling-window front end
 // ---------------------------------------------------------------------------
-constexpr int STRIP_W = 60;  // output columns per wavefront (lanes 2..61)
+constexpr int STRIP_W = 64;  // one wavefront = 64 output columns: every store instruction is one aligned KiB
 
 struct StreamArgs {
     const uint16_t* cfa;   // row 0 = frame row y0 - 2
@@ -171,6 +177,23 @@ struct StreamArgs {
     DeviceEdit ed;
     uint32_t strips, seg_pairs, nitems;
 };
+
+// One CFA row of a strip as the wavefront sees it: v = this lane's sample; p1 / p2 = the W+E sums at
+// distance 1 / 2 of the 5x5 stencil.  The four samples outside the wavefront's 64 columns are the halo
+// h: lanes 0,1 hold columns x0-2, x0-1 and lanes 62,63 hold x0+64, x0+65 (other lanes: don't care).
+struct RowTaps { float v, p1, p2; };
+__device__ __forceinline__ RowTaps row_taps(float v, float h, bool need_p2)
+{
+    const float hl1 = from_right(h, h);        // lane 0  <- lane 1's halo  (column x0-1)
+    const float hr1 = from_left(h, h);         // lane 63 <- lane 62's halo (column x0+64)
+    const float l1 = from_left(v, hl1);        // x-1
+    const float r1 = from_right(v, hr1);       // x+1
+    RowTaps t;
+    t.v = v;
+    t.p1 = l1 + r1;
+    t.p2 = need_p2 ? from_left(l1, h) + from_right(r1, h) : 0.0f;  // x-2 (lane 0: own halo x0-2), x+2 (lane 63: x0+65)
+    return t;
+}
 
 template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
 __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
@@ -193,25 +216,21 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + (tid >> 6));
     const uint32_t nwaves = gridDim.x * (NT / 64);
 
-    // Work distribution: with a ticket counter every wavefront draws the next strip segment (a queue that
-    // drains: each draw is >= the previous, the loop ends at the first draw >= nitems); without one the
-    // items are dealt round-robin.  Either way the loop bound is wave-uniform.
-    uint32_t* const ticket = MODE == MODE_DEVELOP ? a.ed.ticket : nullptr;
-    auto next_item = [&](uint32_t prev) -> uint32_t {
-        if (!ticket) return prev + nwaves;
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(ticket, 1u);
-        return __builtin_amdgcn_readfirstlane(t);
-    };
-    for (uint32_t item = ticket ? next_item(0) : wave; item < a.nitems; item = next_item(item)) {
+    // Every item (64 columns x 2*seg_pairs rows) costs the same number of instructions whatever the
+    // image holds, so the items are dealt round-robin: wave-uniform loop, no queue.
+    for (uint32_t item = wave; item < a.nitems; item += nwaves) {
         const uint32_t seg = item / a.strips, strip = item - seg * a.strips;
         const int x0 = (int)strip * STRIP_W;
         const int pair0 = (int)(seg * a.seg_pairs);
         const int npairs = min((int)a.seg_pairs, total_pairs - pair0);
-        const int xl = x0 - 2 + lane;  // this lane's column (lanes 0,1,62,63: apron)
+        const int xl = x0 + lane;  // this lane's column
         int gx = reflect101(xl, W);
         gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);  // columns past a ragged strip: unused
-        const int cx = (gx + a.raw.xo) & 1;
+        // halo column of the edge lanes; same RGGB column parity as the lane's own column
+        int hx = lane < 2 ? xl - 2 : (lane >= 62 ? xl + 2 : xl);
+        hx = reflect101(hx, W);
+        hx = hx < 0 ? 0 : (hx > W - 1 ? W - 1 : hx);
+        const int cx = (xl + a.raw.xo) & 1;
         // normalisation constants of this lane's column for even / odd window positions
         const int cyE = bp, cyO = bp ^ 1;
         const float blkE = cyE ? (cx ? a.raw.black[3] : a.raw.black[2]) : (cx ? a.raw.black[1] : a.raw.black[0]);
@@ -221,55 +240,51 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
         const float rngO = cyO ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
         const float sclO = cyO ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
 
-        // band-relative row ry (any integer) -> raw sample of this lane's column
-        auto load_row = [&](int ry) -> uint32_t {
+        // band-relative row ry (any integer) -> raw samples of this lane's column and of its halo column
+        auto row_ptr = [&](int ry) -> const uint16_t* {
             int gy = reflect101(y0 + ry, H);
             int br = gy - (y0 - 2);
             br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);  // rows past a ragged band: unused
-            return a.cfa[(size_t)br * W + gx];
+            return a.cfa + (size_t)br * W;
         };
         auto normE = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkE, 0.0f), rngE) * sclE; };
         auto normO = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkO, 0.0f), rngO) * sclO; };
 
-        // window position i <-> band row 2*pair - 2 + i.  v: samples, p1/p2: W+E sums at distance 1 / 2.
+        // window position i <-> band row 2*pair - 2 + i
         const int rbase = 2 * pair0 - 2;
-        float v0 = normE(load_row(rbase + 0)), v1 = normO(load_row(rbase + 1));
-        float v2 = normE(load_row(rbase + 2)), v3 = normO(load_row(rbase + 3));
-        uint32_t n4 = load_row(rbase + 4), n5 = load_row(rbase + 5);
-        float l, r, p1_1, p1_2, p1_3, p2_2, p2_3;
-        l = from_left(v1, v1); r = from_right(v1, v1); p1_1 = l + r;
-        l = from_left(v2, v2); r = from_right(v2, v2); p1_2 = l + r;
-        p2_2 = from_left(l, l) + from_right(r, r);
-        l = from_left(v3, v3); r = from_right(v3, v3); p1_3 = l + r;
-        p2_3 = from_left(l, l) + from_right(r, r);
+        const uint16_t* q0 = row_ptr(rbase + 0);
+        const uint16_t* q1 = row_ptr(rbase + 1);
+        const uint16_t* q2 = row_ptr(rbase + 2);
+        const uint16_t* q3 = row_ptr(rbase + 3);
+        const uint16_t* q4 = row_ptr(rbase + 4);
+        const uint16_t* q5 = row_ptr(rbase + 5);
+        const float v0 = normE(q0[gx]);
+        RowTaps t1 = row_taps(normO(q1[gx]), normO(q1[hx]), false);
+        RowTaps t2 = row_taps(normE(q2[gx]), normE(q2[hx]), true);
+        RowTaps t3 = row_taps(normO(q3[gx]), normO(q3[hx]), true);
+        uint32_t n4 = q4[gx], n4h = q4[hx], n5 = q5[gx], n5h = q5[hx];
+        float w0 = v0;
 
-        const bool col_live = lane >= 2 && lane < 2 + STRIP_W && xl < W;
+        const bool col_live = xl < W;
         for (int p = 0; p < npairs; ++p) {  // wave-uniform
-            const float v4 = normE(n4), v5 = normO(n5);
+            const RowTaps t4 = row_taps(normE(n4), normE(n4h), true);
+            const RowTaps t5 = row_taps(normO(n5), normO(n5h), true);
             if (p + 1 < npairs) {  // prefetch the next step's two rows
-                n4 = load_row(rbase + 2 * p + 6);
-                n5 = load_row(rbase + 2 * p + 7);
+                const uint16_t* qa = row_ptr(rbase + 2 * p + 6);
+                const uint16_t* qb = row_ptr(rbase + 2 * p + 7);
+                n4 = qa[gx]; n4h = qa[hx]; n5 = qb[gx]; n5h = qb[hx];
             }
-            l = from_left(v4, v4); r = from_right(v4, v4);
-            const float p1_4 = l + r;
-            const float p2_4 = from_left(l, l) + from_right(r, r);
-            l = from_left(v5, v5); r = from_right(v5, v5);
-            const float p1_5 = l + r;
-            const float p2_5 = from_left(l, l) + from_right(r, r);
-
             // neighbourhood sums: top pixel = window position 2, bottom = 3
-            const float c[2] = {v2, v3};
-            const float s1[2] = {v1 + v3, v2 + v4};
-            const float e1[2] = {p1_2, p1_3};
-            const float d[2] = {p1_1 + p1_3, p1_2 + p1_4};
-            const float vv[2] = {v0 + v4, v1 + v5};
-            const float h2[2] = {p2_2, p2_3};
+            const float c[2] = {t2.v, t3.v};
+            const float s1[2] = {t1.v + t3.v, t2.v + t4.v};
+            const float e1[2] = {t2.p1, t3.p1};
+            const float d[2] = {t1.p1 + t3.p1, t2.p1 + t4.p1};
+            const float vv[2] = {w0 + t4.v, t1.v + t5.v};
+            const float h2[2] = {t2.p2, t3.p2};
             finish_pair<MODE, LDS_LUT, OUTFMT>(c, s1, e1, d, vv, h2, cx, bp, a.raw, a.ed, luts, *T, xl, 2 * (pair0 + p), a.g,
                                                col_live, a.out);
             // slide the window down two rows
-            v0 = v2; v1 = v3; v2 = v4; v3 = v5;
-            p1_1 = p1_3; p1_2 = p1_4; p1_3 = p1_5;
-            p2_2 = p2_4; p2_3 = p2_5;
+            w0 = t2.v; t1 = t3; t2 = t4; t3 = t5;
         }
     }
 }
@@ -467,7 +482,8 @@ static hipError_t check_edit(const DeviceEdit& ed)
 
 template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
 static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
-                             const DeviceEdit* ed, void* d_out, hipStream_t s)
+                             const DeviceEdit* ed, void* d_out, hipStream_t s, uint32_t seg_pairs = 0,
+                             uint32_t blocks_per_cu = 0)
 {
     StreamArgs a;
     memset(&a, 0, sizeof(a));
@@ -475,8 +491,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     if (ed) a.ed = *ed;
     const uint32_t total_pairs = (g.rows + 1) / 2;
     a.strips = (g.width + STRIP_W - 1) / STRIP_W;
-    // rows per wave-item: 8 pairs amortise the 4-row window prologue (20 row loads per 16 rows)
-    a.seg_pairs = MODE == MODE_DEVELOP ? 4 : 8;
+    a.seg_pairs = seg_pairs ? seg_pairs : 4;  // 8 rows per item: measured best for both modes (profiles/r01_experiments.md)
     const uint32_t segs = (total_pairs + a.seg_pairs - 1) / a.seg_pairs;
     a.nitems = a.strips * segs;
     const size_t lds = MODE == MODE_DEVELOP ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
@@ -486,13 +501,12 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     constexpr uint32_t WPB = NT / 64;
     uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
     if (MODE == MODE_DEVELOP) {
-        // persistent workgroups (LDS tables staged once) fed by the ticket queue: as many as are resident
+        // persistent workgroups (LDS tables staged once per workgroup), as many as are resident
         const uint32_t cap = (uint32_t)cfg.num_cus * (LDS_LUT ? 1u : (uint32_t)(1024 / NT));
         if (grid > cap) grid = cap;
-        if (a.ed.ticket) {
-            e = hipMemsetAsync(a.ed.ticket, 0, sizeof(uint32_t), s);
-            if (e != hipSuccess) return e;
-        }
+    } else if (blocks_per_cu) {
+        const uint32_t cap = (uint32_t)cfg.num_cus * blocks_per_cu;
+        if (grid > cap) grid = cap;
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
     return hipGetLastError();
@@ -527,7 +541,17 @@ hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const Ra
     if (e != hipSuccess) return e;
     if (!d_cfa || !d_rgba) return hipErrorInvalidValue;
     if (cfg.variant == 1) return run_tile<512, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, 4, s);
-    return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s);
+    switch (cfg.variant) {  // measurement variants (bench.py --variant); 0 is the shipped configuration
+    case 2: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 16);
+    case 3: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32_PLAIN>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
+    case 5: return run_stream<512, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
+    case 6: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 2);
+    case 4: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
+    case 7: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8, 8);
+    case 8: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 32);
+    case 9: return run_stream<64, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
+    default: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s);
+    }
 }
 
 template <int OUTFMT>

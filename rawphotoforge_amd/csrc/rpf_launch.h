@@ -16,7 +16,6 @@ struct DeviceEdit {
     const MathTables* tabs;
     float vign_strength;         // (-vignette / 100) * 2, 0 = off       wgsl:167
     float lens_strength;         // -0.5 * (lens_distortion / 100), 0 = off   wgsl:110
-    uint32_t* ticket;            // device counter for the work queue of the fused kernel (zeroed per launch), or null
 };
 
 struct TileGeom {
