@@ -28,7 +28,7 @@
 
 namespace rpf {
 
-enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1 };
+enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2 };  // _SEQ (A/B only): the pair one pixel after the other
 enum { OUT_RGBA_F32_PLAIN = 3 };  // internal (A/B only): RGBA32F with ordinary stores
 
 // ---------------------------------------------------------------------------
@@ -148,7 +148,7 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
         live[k] = col_live && ry_top + k < rows;
         pix[k] = live[k] ? (size_t)(ry_top + k) * W + gx : 0;
     }
-    if (MODE == MODE_DEVELOP) {
+    if (MODE != MODE_DEMOSAIC) {
         if (ed.vign_strength != 0.0f) {  // wgsl:166-178, global coordinates
             for (int k = 0; k < 2; ++k) {
                 const float gain = vignette_gain(ed.vign_strength, gx, (int)g.y0 + ry_top + k, (float)W, (float)g.height);
@@ -158,7 +158,16 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
         uint32_t active[2] = {1u, 1u};
         if (ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(ed, pix[k], (size_t)rows * W);
-        edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
+        if (MODE == MODE_DEVELOP_SEQ) {
+            for (int k = 0; k < 2; ++k) {
+                float r1[1] = {r[k]}, g1[1] = {gg[k]}, b1[1] = {b[k]};
+                const uint32_t a1[1] = {active[k]};
+                edit_chain<1>(r1, g1, b1, a1, ed.mp, ed.num_masks, luts, T);
+                r[k] = r1[0]; gg[k] = g1[0]; b[k] = b1[0];
+            }
+        } else {
+            edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
+        }
     }
     for (int k = 0; k < 2; ++k)
         if (live[k]) store_px<OUTFMT>(out, pix[k], r[k], gg[k], b[k]);
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
     MathTables* T = reinterpret_cast<MathTables*>(smem);
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
     const int tid = threadIdx.x;
-    if (MODE == MODE_DEVELOP) {
+    if (MODE != MODE_DEMOSAIC) {
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
@@ -494,13 +503,13 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     a.seg_pairs = seg_pairs ? seg_pairs : 4;  // 8 rows per item: measured best for both modes (profiles/r01_experiments.md)
     const uint32_t segs = (total_pairs + a.seg_pairs - 1) / a.seg_pairs;
     a.nitems = a.strips * segs;
-    const size_t lds = MODE == MODE_DEVELOP ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
+    const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
     auto kernel = k_stream<NT, MODE, LDS_LUT, OUTFMT>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     constexpr uint32_t WPB = NT / 64;
     uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
-    if (MODE == MODE_DEVELOP) {
+    if (MODE != MODE_DEMOSAIC) {
         // persistent workgroups (LDS tables staged once per workgroup), as many as are resident
         const uint32_t cap = (uint32_t)cfg.num_cus * (LDS_LUT ? 1u : (uint32_t)(1024 / NT));
         if (grid > cap) grid = cap;
@@ -542,14 +551,8 @@ hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const Ra
     if (!d_cfa || !d_rgba) return hipErrorInvalidValue;
     if (cfg.variant == 1) return run_tile<512, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, 4, s);
     switch (cfg.variant) {  // measurement variants (bench.py --variant); 0 is the shipped configuration
-    case 2: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 16);
-    case 3: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32_PLAIN>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
-    case 5: return run_stream<512, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
-    case 6: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 2);
+    case 3: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32_PLAIN>(cfg, d_cfa, raw, g, nullptr, d_rgba, s);
     case 4: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
-    case 7: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8, 8);
-    case 8: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 32);
-    case 9: return run_stream<64, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s, 8);
     default: return run_stream<256, MODE_DEMOSAIC, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, nullptr, d_rgba, s);
     }
 }
@@ -565,6 +568,8 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     if (cfg.variant == 2)  // streaming, 512-thread workgroups
         return lut ? run_stream<512, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                    : run_stream<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    if (OUTFMT == OUT_RGBA_F32 && !lut && cfg.variant == 3)  // A/B: the pixel pair one after the other
+        return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
 }
