@@ -19,6 +19,10 @@ enum MaskFlags : uint32_t {
     MF_HUE_IDENTITY = 1u << 4,     // hue_curve[i] == i
     MF_SAT_CONST = 1u << 5,        // saturation_curve constant -> sat_gain
     MF_LIGHT_CONST = 1u << 6,      // lightness_curve constant -> light_gain
+    // exact no-ops the kernel may skip: x * 1.0f == x and 1.0f + 0.0f * m == 1.0f for every finite m
+    MF_UNITY_WB = 1u << 7,         // r_gain == g_gain == b_gain == 1
+    MF_UNITY_EXPOSURE = 1u << 8,   // pow(2, exposure) == 1
+    MF_NO_SHADOW_HIGHLIGHT = 1u << 9,  // shadow == 0 and highlight == 0
 };
 
 // One mask's uniform parameters: GpuEditParameters (gpu_image_processing.rs:18-32)
@@ -161,15 +165,24 @@ RPF_HD void lens_sample(const Fetch& fetch, int w_u, int h_u, int x, int y, floa
 // ---------------------------------------------------------------------------
 #define RPF_F(x) ((float)(x))
 
-// clamp for finite inputs: v_max_f32 / v_min_f32 on the device (full-rate), the oracle's
-// min(max(v, lo), hi) on the host; the two agree on every non-NaN value up to the sign of zero,
-// which no later operation of the chain observes.
+// clamp for finite inputs: one v_med3_f32 on the device, the oracle's min(max(v, lo), hi) on the host;
+// the two agree on every non-NaN value up to the sign of zero, which no later operation of the chain
+// observes.  (Measured issue cost on gfx950: med3 1.8 ns, max+min 3.6 ns, cmp+cndmask x2 7 ns.)
 RPF_HD float clamp01(float v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f);
+    return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
 #else
     return clampf(v, 0.0f, 1.0f);
+#endif
+}
+
+RPF_HD float max0(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaxf(v, 0.0f);
+#else
+    return v > 0.0f ? v : 0.0f;
 #endif
 }
 
@@ -181,16 +194,22 @@ RPF_HD void mask_rgb_stage(const MaskParams& P, uint32_t m, const Luts& luts, fl
 {
     const float inv65535 = (float)(1.0 / 65535.0);
     for (int n = 0; n < N; ++n) {
-        float x = r[n] * P.r_gain, y = g[n] * P.g_gain, z = b[n] * P.b_gain;  // wgsl:285-288
+        float x = r[n], y = g[n], z = b[n];
+        if (!(P.flags & MF_UNITY_WB)) { x *= P.r_gain; y *= P.g_gain; z *= P.b_gain; }  // wgsl:285-288
         // tone(), wgsl:200-259
-        x *= P.exposure_mul; y *= P.exposure_mul; z *= P.exposure_mul;
-        const float luma = x * RPF_F(0.2126) + y * RPF_F(0.7152) + z * RPF_F(0.0722);
-        const float shadow_mask = clamp01(1.0f - luma);
-        const float highlight_mask = clamp01(luma);
-        const float shadow_gain = 1.0f + P.shadow * shadow_mask;
-        x *= shadow_gain; y *= shadow_gain; z *= shadow_gain;
-        const float highlight_gain = 1.0f + P.highlight * highlight_mask;
-        x *= highlight_gain; y *= highlight_gain; z *= highlight_gain;
+        if (!(P.flags & MF_UNITY_EXPOSURE)) { x *= P.exposure_mul; y *= P.exposure_mul; z *= P.exposure_mul; }
+        float highlight_mask = 0.0f;
+        if ((P.flags & (MF_NO_SHADOW_HIGHLIGHT | MF_BLACK | MF_WHITE)) != MF_NO_SHADOW_HIGHLIGHT) {
+            const float luma = x * RPF_F(0.2126) + y * RPF_F(0.7152) + z * RPF_F(0.0722);
+            highlight_mask = clamp01(luma);
+            if (!(P.flags & MF_NO_SHADOW_HIGHLIGHT)) {
+                const float shadow_mask = clamp01(1.0f - luma);
+                const float shadow_gain = 1.0f + P.shadow * shadow_mask;
+                x *= shadow_gain; y *= shadow_gain; z *= shadow_gain;
+                const float highlight_gain = 1.0f + P.highlight * highlight_mask;
+                x *= highlight_gain; y *= highlight_gain; z *= highlight_gain;
+            }
+        }
         if (P.flags & MF_BLACK) {
             const float t1 = 1.0f - highlight_mask;
             const float add = P.black * (t1 * t1);  // pow(1 - t, 2.0) correctly rounded
@@ -240,9 +259,9 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         const float l = RPF_F(0.4122214708) * r[n] + RPF_F(0.5363325363) * g[n] + RPF_F(0.0514459929) * b[n];
         const float mm = RPF_F(0.2119034982) * r[n] + RPF_F(0.6806995451) * g[n] + RPF_F(0.1073969566) * b[n];
         const float s = RPF_F(0.0883024619) * r[n] + RPF_F(0.2817188376) * g[n] + RPF_F(0.6299787005) * b[n];
-        const float lc = powc<POW_CBRT>(l, T.cbrt);  // powc returns 0 for x <= 0 == pow(max(x, 0), 1/3)
-        const float mc = powc<POW_CBRT>(mm, T.cbrt);
-        const float sc = powc<POW_CBRT>(s, T.cbrt);
+        const float lc = powc<POW_CBRT>(max0(l), T.cbrt);  // pow(max(lms, 0), 1/3), wgsl:67
+        const float mc = powc<POW_CBRT>(max0(mm), T.cbrt);
+        const float sc = powc<POW_CBRT>(max0(s), T.cbrt);
         L[n] = RPF_F(0.2104542553) * lc + RPF_F(0.7936177850) * mc + RPF_F(-0.0040720468) * sc;
         const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
         const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;

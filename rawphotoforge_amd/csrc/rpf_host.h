@@ -168,6 +168,9 @@ inline MaskParams make_mask_params(const EditParameters& p)
     if (g.black != 0.0f) f |= MF_BLACK;
     if (g.white != 0.0f) f |= MF_WHITE;
     if (g.contrast != 0.0f) f |= MF_CONTRAST;
+    if (m.r_gain == 1.0f && m.g_gain == 1.0f && m.b_gain == 1.0f) f |= MF_UNITY_WB;
+    if (m.exposure_mul == 1.0f) f |= MF_UNITY_EXPOSURE;
+    if (g.shadow == 0.0f && g.highlight == 0.0f) f |= MF_NO_SHADOW_HIGHLIGHT;
     bool ident_b = true, ident_h = true, const_s = true, const_l = true;
     const uint32_t s0 = lut_clamp(p.curve[RPF_CURVE_SATURATION][0]);
     const uint32_t l0 = lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][0]);

@@ -102,7 +102,10 @@ RPF_HD float div_by_const(float x, float d, float rd)
 // Correctly rounded x^c for x >= 0 (c fixed by KIND).  Exhaustively equal to the oracle's
 // cr_powf on [2^-21, 1.25) for cbrt and [2^-9, 2^3) for gamma; same algorithm (rel. error
 // < 2^-50 before the single rounding) on the rest of the binary32 range.
-// x <= 0 -> 0 (so pow(max(x, 0), c) needs no separate max); inputs must be finite.
+// Finite x >= 0 only.  x = 0 has a zero exponent field, lands on table entry 0 (below every binary32
+// exponent) which holds 0.0, so pow(0, c) = 0 falls out of the same multiplications with no select;
+// a negative x returns |x|^c (the chain never uses that value: wgsl:67 takes max(x, 0), wgsl:98 the
+// linear branch).
 template <int KIND, class TabT>
 RPF_HD float powc(float x, const TabT& T)
 {
@@ -112,7 +115,7 @@ RPF_HD float powc(float x, const TabT& T)
     const uint32_t ebits = (hi >> 20) & 0x7ffu;
     const uint32_t j = (hi >> 13) & 127u;
     int ei = (int)ebits - (1023 + RPF_POW_EMIN);
-    ei = ei < 0 ? 0 : (ei > RPF_POW_ECNT - 1 ? RPF_POW_ECNT - 1 : ei);
+    ei = ei < 0 ? 0 : ei;  // finite binary32 never exceeds the table (2^127 -> entry 287)
     const double m = hilo2d((hi & 0x000fffffu) | 0x3ff00000u, (uint32_t)u);
     const double r = T.TR[j][1];
     const double tj = T.TR[j][0];
@@ -123,8 +126,7 @@ RPF_HD float powc(float x, const TabT& T)
     p = __builtin_fma(t, p, K::c2);
     p = __builtin_fma(t, p, K::c1);
     p = __builtin_fma(t, p, 1.0);
-    const float y = (float)((T.E[ei] * tj) * p);
-    return x > 0.0f ? y : 0.0f;  // finite inputs only (inf/NaN in -> unspecified out)
+    return (float)((T.E[ei] * tj) * p);
 }
 
 // atan(q) = q + q^3 P(q^2), |q| <= tan(pi/8); rel. error 2^-52.7 (tools/gen_math_consts.py)
@@ -162,7 +164,13 @@ RPF_HD float atan2_cr(float y, float x)
     const int E = (int)((dhi >> 20) & 0x7ffu) - 1023;
     const double d1 = hilo2d((dhi & 0x000fffffu) | 0x3ff00000u, (uint32_t)ud);  // den == 0 -> 1.0, num == 0
     const double n1 = __builtin_ldexp(num, -E);
-    const float rc = 1.0f / (float)d1;  // IEEE binary32 division, rel. error 2^-23
+    // 1/d1 to ~2^-22 by three binary32 Newton steps from the linear seed 24/17 - 8/17 d (error 1/17 ->
+    // 3.5e-3 -> 1.2e-5 -> 1.4e-10, then rounding): 7 full-rate fma instead of an IEEE division sequence
+    const float df = (float)d1;
+    float rc = __builtin_fmaf(df, -0x1.e1e1e2p-2f, 0x1.696969p+0f);
+    rc = __builtin_fmaf(rc, __builtin_fmaf(-df, rc, 1.0f), rc);
+    rc = __builtin_fmaf(rc, __builtin_fmaf(-df, rc, 1.0f), rc);
+    rc = __builtin_fmaf(rc, __builtin_fmaf(-df, rc, 1.0f), rc);
     const double q0 = n1 * (double)rc;
     const double res = __builtin_fma(-q0, d1, n1);
     const double q = __builtin_fma(res, (double)rc, q0);  // rel. error ~2^-46 of a 2^-23 term

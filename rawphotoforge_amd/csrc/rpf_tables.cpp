@@ -11,6 +11,7 @@ static void build_pow(PowTable& P, float cf)
     const long double c = (long double)cf;
     for (int e = RPF_POW_EMIN; e < RPF_POW_EMIN + RPF_POW_ECNT; ++e)
         P.E[e - RPF_POW_EMIN] = (double)powl(2.0L, (long double)e * c);
+    P.E[0] = 0.0;  // 2^-160 is below every binary32: entry 0 is only ever reached by x = 0 (see powc)
     for (int j = 0; j < 128; ++j) {
         const long double mid = 1.0L + ((long double)j + 0.5L) / 128.0L;
         // r_j: reciprocal of the bin centre on a 2^-16 grid, so m * r_j is exact in binary64

@@ -60,6 +60,35 @@ F32_KERNEL(k_dpp_mov, "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0x
            "v_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf",
            "v_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf")
 
+#define U8(fmt) fmt(0), fmt(1), fmt(2), fmt(3), fmt(4), fmt(5), fmt(6), fmt(7)
+F32_KERNEL(k_cnd_vcc, "v_cndmask_b32 %0, %8, %0, vcc", "v_cndmask_b32 %1, %8, %1, vcc", "v_cndmask_b32 %2, %8, %2, vcc",
+           "v_cndmask_b32 %3, %8, %3, vcc", "v_cndmask_b32 %4, %8, %4, vcc", "v_cndmask_b32 %5, %8, %5, vcc",
+           "v_cndmask_b32 %6, %8, %6, vcc", "v_cndmask_b32 %7, %8, %7, vcc")
+F32_KERNEL(k_add_u32, "v_add_u32 %0, %8, %0", "v_add_u32 %1, %8, %1", "v_add_u32 %2, %8, %2", "v_add_u32 %3, %8, %3",
+           "v_add_u32 %4, %8, %4", "v_add_u32 %5, %8, %5", "v_add_u32 %6, %8, %6", "v_add_u32 %7, %8, %7")
+F32_KERNEL(k_lshr, "v_lshrrev_b32 %0, 3, %0", "v_lshrrev_b32 %1, 3, %1", "v_lshrrev_b32 %2, 3, %2", "v_lshrrev_b32 %3, 3, %3",
+           "v_lshrrev_b32 %4, 3, %4", "v_lshrrev_b32 %5, 3, %5", "v_lshrrev_b32 %6, 3, %6", "v_lshrrev_b32 %7, 3, %7")
+F32_KERNEL(k_max_f32, "v_max_f32 %0, %8, %0", "v_max_f32 %1, %8, %1", "v_max_f32 %2, %8, %2", "v_max_f32 %3, %8, %3",
+           "v_max_f32 %4, %8, %4", "v_max_f32 %5, %8, %5", "v_max_f32 %6, %8, %6", "v_max_f32 %7, %8, %7")
+F32_KERNEL(k_med3_f32, "v_med3_f32 %0, %0, %8, %9", "v_med3_f32 %1, %1, %8, %9", "v_med3_f32 %2, %2, %8, %9", "v_med3_f32 %3, %3, %8, %9",
+           "v_med3_f32 %4, %4, %8, %9", "v_med3_f32 %5, %5, %8, %9", "v_med3_f32 %6, %6, %8, %9", "v_med3_f32 %7, %7, %8, %9")
+F32_KERNEL(k_bfe_u32, "v_bfe_u32 %0, %0, 3, 7", "v_bfe_u32 %1, %1, 3, 7", "v_bfe_u32 %2, %2, 3, 7", "v_bfe_u32 %3, %3, 3, 7",
+           "v_bfe_u32 %4, %4, 3, 7", "v_bfe_u32 %5, %5, 3, 7", "v_bfe_u32 %6, %6, 3, 7", "v_bfe_u32 %7, %7, 3, 7")
+F32_KERNEL(k_cmp_f32, "v_cmp_lt_f32 vcc, %8, %0", "v_cmp_lt_f32 vcc, %8, %1", "v_cmp_lt_f32 vcc, %8, %2", "v_cmp_lt_f32 vcc, %8, %3",
+           "v_cmp_lt_f32 vcc, %8, %4", "v_cmp_lt_f32 vcc, %8, %5", "v_cmp_lt_f32 vcc, %8, %6", "v_cmp_lt_f32 vcc, %8, %7")
+F32_KERNEL(k_mov_b32, "v_mov_b32 %0, %8", "v_mov_b32 %1, %9", "v_mov_b32 %2, %8", "v_mov_b32 %3, %9",
+           "v_mov_b32 %4, %8", "v_mov_b32 %5, %9", "v_mov_b32 %6, %8", "v_mov_b32 %7, %9")
+F32_KERNEL(k_mul_sgpr, "v_mul_f32 %0, s20, %0", "v_mul_f32 %1, s20, %1", "v_mul_f32 %2, s20, %2", "v_mul_f32 %3, s20, %3",
+           "v_mul_f32 %4, s20, %4", "v_mul_f32 %5, s20, %5", "v_mul_f32 %6, s20, %6", "v_mul_f32 %7, s20, %7")
+F32_KERNEL(k_mul_lit, "v_mul_f32 %0, 0x3f9e3779, %0", "v_mul_f32 %1, 0x3f9e3779, %1", "v_mul_f32 %2, 0x3f9e3779, %2", "v_mul_f32 %3, 0x3f9e3779, %3",
+           "v_mul_f32 %4, 0x3f9e3779, %4", "v_mul_f32 %5, 0x3f9e3779, %5", "v_mul_f32 %6, 0x3f9e3779, %6", "v_mul_f32 %7, 0x3f9e3779, %7")
+F32_KERNEL(k_fma_sgpr, "v_fma_f32 %0, %8, s20, %0", "v_fma_f32 %1, %8, s20, %1", "v_fma_f32 %2, %8, s20, %2", "v_fma_f32 %3, %8, s20, %3",
+           "v_fma_f32 %4, %8, s20, %4", "v_fma_f32 %5, %8, s20, %5", "v_fma_f32 %6, %8, s20, %6", "v_fma_f32 %7, %8, s20, %7")
+F32_KERNEL(k_readlane, "v_readlane_b32 s20, %0, 3", "v_readlane_b32 s21, %1, 3", "v_readlane_b32 s22, %2, 3", "v_readlane_b32 s23, %3, 3",
+           "v_readlane_b32 s24, %4, 3", "v_readlane_b32 s25, %5, 3", "v_readlane_b32 s26, %6, 3", "v_readlane_b32 s27, %7, 3")
+F32_KERNEL(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %0", "v_cvt_f32_u32 %1, %1", "v_cvt_f32_u32 %2, %2", "v_cvt_f32_u32 %3, %3",
+           "v_cvt_f32_u32 %4, %4", "v_cvt_f32_u32 %5, %5", "v_cvt_f32_u32 %6, %6", "v_cvt_f32_u32 %7, %7")
+
 // 64-bit operand kernels: accumulators are doubles / float2
 #define F64_KERNEL(NAME, T, INIT, I0, I1, I2, I3, I4, I5, I6, I7)                                           \
     __global__ void NAME(float* out, long long* cyc, T x, T y)                                               \
@@ -220,6 +249,19 @@ int main()
     run("v_lshl_add_u32", k_lshl_add, 0, 1.0001f, 0.5f);
     run("v_cndmask_b32", k_cndmask, 0, 1.0001f, 0.5f);
     run("v_mov_dpp", k_dpp_mov, 0, 1.0001f, 0.5f);
+    run("cndmask vcc", k_cnd_vcc, 0, 1.0001f, 0.5f);
+    run("v_add_u32", k_add_u32, 0, 1.0001f, 0.5f);
+    run("v_lshrrev_b32", k_lshr, 0, 1.0001f, 0.5f);
+    run("v_max_f32", k_max_f32, 0, 1.0001f, 0.5f);
+    run("v_med3_f32", k_med3_f32, 0, 1.0001f, 0.5f);
+    run("v_bfe_u32", k_bfe_u32, 0, 1.0001f, 0.5f);
+    run("v_cmp_lt_f32", k_cmp_f32, 0, 1.0001f, 0.5f);
+    run("v_mov_b32", k_mov_b32, 0, 1.0001f, 0.5f);
+    run("v_mul_f32 sgpr", k_mul_sgpr, 0, 1.0001f, 0.5f);
+    run("v_mul_f32 lit", k_mul_lit, 0, 1.0001f, 0.5f);
+    run("v_fma_f32 sgpr", k_fma_sgpr, 0, 1.0001f, 0.5f);
+    run("v_readlane", k_readlane, 0, 1.0001f, 0.5f);
+    run("v_cvt_f32_u32", k_cvt_f32_u32, 0, 1.0001f, 0.5f);
     printf("LDS random gathers over 128 KiB (cycles per wave-instruction per CU-quarter; includes ~4 address VALU ops)\n");
     run("ds_read_u16", k_lds_gather<2>, 131072, 1.0f, 0.5f);  // k = 1 only
     run("ds_read_b64", k_lds_gather<8>, 131072, 1.0f, 0.5f);
