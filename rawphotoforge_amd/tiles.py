@@ -61,3 +61,69 @@ def make_band_buffer(cfa_band, device=None):
     pad[HALO:HALO + rows] = cfa_band
     t = torch.from_numpy(pad.view(np.int16))
     return t.to(device) if device is not None else t
+
+
+class BandDeveloper:
+    """One rank's band of a row-tiled frame through the fused kernel, with the halo exchange hidden
+    behind the interior rows.
+
+    Only the first/last EDGE rows of a band read halo rows; the interior never does.  Per step:
+    the interior tile is launched on a side stream, the 2-row halos are exchanged with the neighbours
+    (RCCL send/recv on the current stream), the two EDGE-row tiles run after the exchange, and the
+    streams are joined.  With world == 1 (or overlap=False) it is one launch on the current stream.
+    All three tiles are views of the same band / output buffers (rpf_dev_develop takes raw pointers).
+    """
+
+    EDGE = 8  # rows per edge tile = one work item of the kernel (64 columns x 8 rows)
+
+    def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, rank=0, world=1, overlap=True):
+        import torch
+
+        from .editor import PhotoEditor
+
+        self.raw, self.rank, self.world = raw, rank, world
+        self.w, self.rows = frame_width, rows
+        self.split = overlap and world > 1 and rows >= 4 * self.EDGE
+        self._torch = torch
+        e = self.EDGE
+        parts = [(0, rows)] if not self.split else [(e, rows - 2 * e), (0, e), (rows - e, e)]
+        self.parts = []
+        for off, n in parts:  # (row offset inside the band, rows): interior first
+            ed = PhotoEditor.for_tile(gpu, frame_width, frame_height, y0 + off, n)
+            configure(ed)
+            self.parts.append((off, n, ed))
+        self.side = torch.cuda.Stream() if self.split else None
+
+    def step(self, band, out, out_format=0, bytes_per_px=16, exchange=True, events=None):
+        """band: (rows + 4, W) 2-byte tensor with halo rows; out: rows x W pixels.  `events`: optional
+        (start, end) CUDA events recorded around the dominant (interior / whole-band) launch."""
+        torch = self._torch
+        cur = torch.cuda.current_stream()
+        bptr, optr = band.data_ptr(), out.data_ptr()
+        row_in, row_out = self.w * 2, self.w * bytes_per_px
+
+        def launch(part, stream):
+            off, _, ed = part
+            ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, stream.cuda_stream)
+
+        if not self.split:
+            if exchange:
+                exchange_halos(band, self.rank, self.world)
+            if events:
+                events[0].record(cur)
+            launch(self.parts[0], cur)
+            if events:
+                events[1].record(cur)
+            return
+        self.side.wait_stream(cur)  # the previous step's readers/writers of band/out are done
+        with torch.cuda.stream(self.side):
+            if events:
+                events[0].record(self.side)
+            launch(self.parts[0], self.side)
+            if events:
+                events[1].record(self.side)
+        if exchange:
+            exchange_halos(band, self.rank, self.world)
+        launch(self.parts[1], cur)
+        launch(self.parts[2], cur)
+        cur.wait_stream(self.side)

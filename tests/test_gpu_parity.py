@@ -281,3 +281,84 @@ def test_full_size_6000x4000(gpu):
         assert (host[..., 3] == 1).all() and host[..., :3].min() >= 0 and host[..., :3].max() <= 1
         for y0 in (0, 1996, h - 8):
             assert_parity(host[y0:y0 + 8], O.develop(cfa, rp, [p], y0=y0, rows=8))
+
+
+def test_band_developer_overlap_split_equals_oracle(gpu):
+    """The N > 1 step (interior tile on a side stream, edge tiles after the halo exchange) on one GPU: the
+    halos are pre-filled instead of exchanged; the three tiles must tile the band exactly."""
+    torch = pytest.importorskip("torch")
+    from rawphotoforge_amd import synthetic as syn
+    from rawphotoforge_amd import tiles
+    h, w = 230, 300
+    cfa = util.bayer_natural(h, w)
+    rp = util.raw_params()
+    want = O.develop(cfa, rp, [util.params_S()])
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    for rank, (y0, rows) in enumerate(((0, 70), (70, 96), (166, 64))):
+        band = torch.from_numpy(pad[y0:y0 + rows + 4].copy().view(np.int16)).cuda()
+        out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+        bd = tiles.BandDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, syn.PARAM_SETS["S"]),
+                                 rank=rank, world=3, overlap=True)
+        assert bd.split and [n for _, n, _ in bd.parts] == [rows - 16, 8, 8]
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for _ in range(3):   # repeated steps: stream joins must order the reuse of band/out
+            bd.step(band, out, R.OUT_RGBA_F32, 16, exchange=False, events=ev)
+        torch.cuda.synchronize()
+        assert ev[0].elapsed_time(ev[1]) > 0
+        assert_parity(out.cpu().numpy(), want[y0:y0 + rows])
+        single = tiles.BandDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, syn.PARAM_SETS["S"]),
+                                     rank=rank, world=3, overlap=False)
+        out2 = torch.zeros_like(out)
+        single.step(band, out2, R.OUT_RGBA_F32, 16, exchange=False)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2)
+
+
+def test_empty_and_invalid_inputs(gpu):
+    with pytest.raises(R.FailedToReadImage):
+        R.PhotoEditor.new_from_rgb_f32(gpu, np.zeros(0, np.float32), 0, 0)
+    with pytest.raises(R.FailedToReadImage):
+        R.PhotoEditor.new_from_bayer_u16(gpu, np.zeros((2, 2), np.uint16), util.to_raw(util.raw_params()))
+    with pytest.raises(R.FailedToReadImage):   # white level must exceed black level
+        R.PhotoEditor.new_from_bayer_u16(gpu, np.zeros((8, 8), np.uint16), R.RawParams(black=(512,) * 4, white=512))
+    with pytest.raises(R.InvalidArgument):
+        R.PhotoEditor.for_tile(gpu, 64, 64, 60, 8)      # tile leaves its frame
+    ed = R.PhotoEditor.for_tile(gpu, 64, 64, 0, 64)
+    with pytest.raises(R.GpuComputeError):
+        ed.apply_adjustments()                          # a tile editor owns no image
+    ed.set_lens_distortion_correction(10)
+    with pytest.raises(R.InvalidArgument):
+        ed.dev_develop(1, util.to_raw(util.raw_params()), 1)   # resampling cannot run on the fused tile path
+    one = R.PhotoEditor.new_from_rgb_f32(gpu, np.float32([0.25, 0.5, 0.75]), 1, 1)   # 1x1 image
+    one.apply_adjustments()
+    want = O.apply(np.float32([[[0.25, 0.5, 0.75, 1.0]]]), [O.EditParameters()])
+    assert_parity(one.rgba(), want)
+
+
+def test_maximum_size_12000x8000(gpu):
+    """BASELINE configs[3] frame on one GPU: bands with halos == whole frame, oracle on sampled bands."""
+    torch = pytest.importorskip("torch")
+    h, w = 8000, 12000
+    cfa = util.bayer_uniform(h, w, seed=4)
+    rp = util.raw_params()
+    p = util.params_S()
+    s = torch.cuda.current_stream().cuda_stream
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    d = torch.from_numpy(pad.view(np.int16)).cuda()
+    ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+    util.configure_editor(ed, p)
+    whole = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    ed.dev_develop(d.data_ptr(), util.to_raw(rp), whole.data_ptr(), R.OUT_RGBA_F32, s)
+    torch.cuda.synchronize()
+    from rawphotoforge_amd import tiles
+    for y0, rows in tiles.split_rows(h, 8):
+        eb = R.PhotoEditor.for_tile(gpu, w, h, y0, rows)
+        util.configure_editor(eb, p)
+        ob = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
+        eb.dev_develop(d[y0:y0 + rows + 4].data_ptr(), util.to_raw(rp), ob.data_ptr(), R.OUT_RGBA_F32, s)
+        torch.cuda.synchronize()
+        assert torch.equal(ob, whole[y0:y0 + rows])
+    for y0 in (0, 3998, h - 4):
+        assert_parity(whole[y0:y0 + 4].cpu().numpy(), O.develop(cfa, rp, [p], y0=y0, rows=4))
