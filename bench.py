@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 
 W, H = 6000, 4000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_PX = {"develop": 18, "demosaic": 18, "apply": 32}   # u16 in + RGBA32F out
+BYTES_PER_PX = {"develop": 18, "demosaic": 18, "apply": 32,   # u16 in + RGBA32F out
+                "unpack": 3.5}                                  # 12-bit packed in (1.5 B) + u16 out
 
 
 def main():
@@ -33,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply"])
+    ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply", "unpack"])
     ap.add_argument("--params", default="D", choices=["D", "S", "G"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
@@ -80,6 +81,10 @@ def main():
         R.dev_demosaic(gpu, band.data_ptr(), praw, W, frame_h, y0, rows, lin.data_ptr(),
                        torch.cuda.current_stream().cuda_stream)
 
+    packed = None
+    if args.workload == "unpack":   # the integer stage in front: 12-bit MSB-first packed -> the band buffer's own rows
+        bits16 = np.unpackbits((cfa & 0x0FFF).astype(">u2").view(np.uint8).reshape(rows, W, 2), axis=2)[:, :, 4:]
+        packed = torch.from_numpy(np.packbits(bits16.reshape(rows, W * 12), axis=1)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -90,7 +95,9 @@ def main():
         tiles.exchange_halos(band, rank, world)          # no-op at N = 1
         if i is not None:
             ev[i][0].record()
-        if args.workload == "demosaic":
+        if args.workload == "unpack":
+            R.dev_unpack_bayer(gpu, packed.data_ptr(), packed.shape[1], W, rows, 12, band[2:].data_ptr(), stream)
+        elif args.workload == "demosaic":
             R.dev_demosaic(gpu, band.data_ptr(), praw, W, frame_h, y0, rows, out.data_ptr(), stream)
         else:
             ed.dev_apply(lin.data_ptr(), out.data_ptr(), R.OUT_RGBA_F32, stream)

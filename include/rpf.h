@@ -192,6 +192,12 @@ typedef struct rpf_tile {
     uint32_t y0, rows;
 } rpf_tile;
 
+/* Packed RAW -> u16 CFA plane (integer, bit-exact).  MSB-first bit stream: sample i of a row occupies bits
+ * [i*bits, (i+1)*bits) counted from the most significant bit of byte 0; rows start every row_stride bytes.
+ * bits in {10, 12, 14, 16}.  d_cfa_out has pitch `width` (write it at row 2 of a band buffer).  In the reference
+ * this step is inside rawler / LibRaw (rust-godot-legacy/photo-editor/src/image.rs:516-523). */
+int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows,
+                         uint32_t bits, uint16_t* d_cfa_out, void* stream);
 /* black level -> WB -> 5x5 demosaic -> camera matrix; linear RGBA32F out */
 int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_params* raw, const rpf_tile* tile,
                      float* d_rgba_out, void* stream);

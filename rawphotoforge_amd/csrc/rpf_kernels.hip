@@ -459,6 +459,57 @@ __global__ __launch_bounds__(256) void k_pad_rgb(const float* in, size_t npix, f
 }
 
 // ---------------------------------------------------------------------------
+// k_unpack — packed RAW (10/12/14/16-bit, MSB-first bit stream) -> u16 CFA plane.  Integer, bit-exact.
+// One thread = 16 samples = 2*BITS bytes read as BITS/2 dwords and two 16-B stores; a group that is
+// ragged (row end) or unaligned goes sample by sample.
+// ---------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, size_t row_stride, uint32_t width, uint32_t rows,
+                                                uint16_t* out, uint32_t groups_per_row)
+{
+    constexpr int NW = BITS / 2;  // dwords per 16-sample group
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const size_t total = (size_t)groups_per_row * rows;
+    const bool aligned = (row_stride & 3u) == 0 && (width & 7u) == 0 && ((size_t)packed & 3u) == 0 && ((size_t)out & 15u) == 0;
+    for (size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (size_t)gridDim.x * 256) {
+        const uint32_t y = (uint32_t)(gi / groups_per_row), g = (uint32_t)(gi - (size_t)y * groups_per_row);
+        const uint8_t* row = packed + (size_t)y * row_stride;
+        uint16_t* orow = out + (size_t)y * width;
+        const uint32_t x0 = g * 16u;
+        if (aligned && x0 + 16u <= width && (size_t)(g + 1) * (2 * BITS) <= row_stride) {
+            uint32_t w[NW + 1];
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(row + (size_t)g * (2 * BITS));
+#pragma unroll
+            for (int k = 0; k < NW; ++k) w[k] = __builtin_bswap32(src[k]);  // big-endian words of the bit stream
+            w[NW] = 0;
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int o = j * BITS, i = o >> 5, sh = o & 31;
+                const uint64_t two = ((uint64_t)w[i] << 32) | w[i + 1];
+                v[j] = (uint32_t)(two >> (64 - sh - BITS)) & MASK;
+            }
+            uint4 a, b;
+            a.x = v[0] | (v[1] << 16); a.y = v[2] | (v[3] << 16); a.z = v[4] | (v[5] << 16); a.w = v[6] | (v[7] << 16);
+            b.x = v[8] | (v[9] << 16); b.y = v[10] | (v[11] << 16); b.z = v[12] | (v[13] << 16); b.w = v[14] | (v[15] << 16);
+            uint4* dst = reinterpret_cast<uint4*>(orow + x0);
+            dst[0] = a; dst[1] = b;
+        } else {
+            for (uint32_t x = x0; x < x0 + 16u && x < width; ++x) {
+                const uint64_t bit = (uint64_t)x * BITS;
+                const size_t by = (size_t)(bit >> 3);
+                const uint32_t sh = (uint32_t)(bit & 7);
+                // BITS + 7 <= 23 bits span at most 3 bytes (4 for 16-bit samples never: sh is 0 there)
+                uint32_t acc = ((uint32_t)row[by] << 16) | ((uint32_t)row[by + 1] << 8);
+                if (sh + BITS > 16) acc |= row[by + 2];
+                orow[x] = (uint16_t)((acc >> (24 - sh - BITS)) & MASK);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 template <class K>
@@ -634,6 +685,25 @@ hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom&
     case OUT_RGB_U8: return apply_fmt<OUT_RGB_U8>(cfg, a, s);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows, uint32_t bits,
+                         uint16_t* d_out, hipStream_t s)
+{
+    if (width == 0 || rows == 0) return hipSuccess;
+    if (!d_packed || !d_out) return hipErrorInvalidValue;
+    if (row_stride < ((size_t)width * bits + 7) / 8) return hipErrorInvalidValue;
+    const uint32_t gpr = (width + 15) / 16;
+    const size_t total = (size_t)gpr * rows;
+    const uint32_t grid = (uint32_t)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    switch (bits) {
+    case 10: hipLaunchKernelGGL(k_unpack<10>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
+    case 12: hipLaunchKernelGGL(k_unpack<12>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
+    case 14: hipLaunchKernelGGL(k_unpack<14>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
+    case 16: hipLaunchKernelGGL(k_unpack<16>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_format, hipStream_t s)

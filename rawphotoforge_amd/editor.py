@@ -364,3 +364,10 @@ def dev_demosaic(processor: GpuProcessor, d_cfa_ptr: int, raw: RawParams, frame_
     t = N.Tile(frame_width, frame_height, y0, rows)
     _check(N.lib().rpf_dev_demosaic(processor._h, C.c_void_p(d_cfa_ptr), C.byref(rp), C.byref(t),
                                     C.c_void_p(d_rgba_ptr), C.c_void_p(stream)))
+
+
+def dev_unpack_bayer(processor: GpuProcessor, d_packed_ptr: int, row_stride: int, width: int, rows: int, bits: int,
+                     d_cfa_ptr: int, stream: int = 0) -> None:
+    """Packed RAW (MSB-first 10/12/14/16-bit) -> u16 CFA plane on the device (rpf_dev_unpack_bayer)."""
+    _check(N.lib().rpf_dev_unpack_bayer(processor._h, C.c_void_p(d_packed_ptr), row_stride, width, rows, bits,
+                                        C.c_void_p(d_cfa_ptr), C.c_void_p(stream)))
