@@ -304,3 +304,11 @@ def unpack_bayer(packed, width: int, bits: int) -> np.ndarray:
     lib().orc_unpack_bayer(_p(p, C.c_uint8), C.c_size_t(stride), C.c_uint32(width), C.c_uint32(rows), C.c_uint32(bits),
                            _p(out, C.c_uint16))
     return out
+
+
+def legacy_tone_lut(exposure=0.0, contrast=0, shadow=0, highlight=0, black=0, white=0) -> np.ndarray:
+    """python-legacy editor.py:712-778 _create_tone_lut_from_params (float32[65536])."""
+    out = np.empty(CURVE_RESOLUTION, np.float32)
+    lib().orc_legacy_tone_lut(C.c_double(exposure), C.c_int(contrast), C.c_int(shadow), C.c_int(highlight),
+                              C.c_int(black), C.c_int(white), _p(out, C.c_float))
+    return out
