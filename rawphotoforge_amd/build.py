@@ -2,7 +2,9 @@
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the parity contract: the
 oracle rounds after every binary32 operation (oracle/rpf_oracle.c), so must the kernels and
-the host-side f32 arithmetic (PCHIP, parameter conversion).
+the host-side f32 arithmetic (PCHIP, parameter conversion).  -fno-slp-vectorize: on gfx950 a v_pk_*_f32
+costs two plain f32 instructions' issue time (tools/microbench.hip), so SLP packing only adds the v_mov
+traffic that builds the register pairs.
 """
 from __future__ import annotations
 
@@ -32,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+        cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
                "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
