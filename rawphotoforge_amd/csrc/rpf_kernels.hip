@@ -249,24 +249,31 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
         const float rngO = cyO ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
         const float sclO = cyO ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
 
-        // band-relative row ry (any integer) -> raw samples of this lane's column and of its halo column
-        auto row_ptr = [&](int ry) -> const uint16_t* {
-            int gy = reflect101(y0 + ry, H);
+        // Row addressing: lane j works out, once per item, the element offset of window row j of this
+        // item (reflect-101 at the frame edge, clamp inside the band buffer); the loop then fetches the two
+        // offsets it needs per step with v_readlane instead of redoing ~20 scalar operations per row on
+        // uniforms that do not fit the SGPR file.  An item spans 2 * seg_pairs + 4 <= 64 rows.
+        const int rbase = 2 * pair0 - 2;
+        uint32_t rowoff;
+        {
+            int gy = reflect101(y0 + rbase + lane, H);
             int br = gy - (y0 - 2);
             br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);  // rows past a ragged band: unused
-            return a.cfa + (size_t)br * W;
+            rowoff = (uint32_t)br * (uint32_t)W;
+        }
+        auto row_ptr = [&](int j) -> const uint16_t* {  // j = window row of the item, wave-uniform
+            return a.cfa + __builtin_amdgcn_readlane(rowoff, j);
         };
         auto normE = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkE, 0.0f), rngE) * sclE; };
         auto normO = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkO, 0.0f), rngO) * sclO; };
 
         // window position i <-> band row 2*pair - 2 + i
-        const int rbase = 2 * pair0 - 2;
-        const uint16_t* q0 = row_ptr(rbase + 0);
-        const uint16_t* q1 = row_ptr(rbase + 1);
-        const uint16_t* q2 = row_ptr(rbase + 2);
-        const uint16_t* q3 = row_ptr(rbase + 3);
-        const uint16_t* q4 = row_ptr(rbase + 4);
-        const uint16_t* q5 = row_ptr(rbase + 5);
+        const uint16_t* q0 = row_ptr(0);
+        const uint16_t* q1 = row_ptr(1);
+        const uint16_t* q2 = row_ptr(2);
+        const uint16_t* q3 = row_ptr(3);
+        const uint16_t* q4 = row_ptr(4);
+        const uint16_t* q5 = row_ptr(5);
         const float v0 = normE(q0[gx]);
         RowTaps t1 = row_taps(normO(q1[gx]), normO(q1[hx]), false);
         RowTaps t2 = row_taps(normE(q2[gx]), normE(q2[hx]), true);
@@ -279,8 +286,8 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
             const RowTaps t4 = row_taps(normE(n4), normE(n4h), true);
             const RowTaps t5 = row_taps(normO(n5), normO(n5h), true);
             if (p + 1 < npairs) {  // prefetch the next step's two rows
-                const uint16_t* qa = row_ptr(rbase + 2 * p + 6);
-                const uint16_t* qb = row_ptr(rbase + 2 * p + 7);
+                const uint16_t* qa = row_ptr(2 * p + 6);
+                const uint16_t* qb = row_ptr(2 * p + 7);
                 n4 = qa[gx]; n4h = qa[hx]; n5 = qb[gx]; n5h = qb[hx];
             }
             // neighbourhood sums: top pixel = window position 2, bottom = 3
