@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--params", default="D", choices=["D", "S", "G"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--out", default="rgba", choices=["rgba", "rgb", "u8"], help="output layout of the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos, then one launch per band")
     ap.add_argument("--cpu-rows", type=int, default=100)
@@ -74,7 +75,10 @@ def main():
     syn.configure(ed, spec)
     dev = tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, lambda e: syn.configure(e, spec), rank, world,
                               overlap=not args.no_overlap)
-    out = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda")
+    out_fmt, out_bpp = {"rgba": (R.OUT_RGBA_F32, 16), "rgb": (R.OUT_RGB_F32, 12), "u8": (R.OUT_RGB_U8, 3)}[args.out]
+    if args.workload != "develop" and args.out != "rgba":
+        raise SystemExit("--out applies to the fused develop workload")
+    out = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda")   # large enough for every layout
     lin = None
     if args.workload == "apply":
         lin = torch.empty_like(out)
@@ -90,7 +94,7 @@ def main():
 
     def step(i=None):
         if args.workload == "develop":   # halo exchange (N > 1) hidden behind the interior rows
-            dev.step(band, out, R.OUT_RGBA_F32, 16, True, ev[i] if i is not None else None)
+            dev.step(band, out, out_fmt, out_bpp, True, ev[i] if i is not None else None)
             return
         tiles.exchange_halos(band, rank, world)          # no-op at N = 1
         if i is not None:
@@ -127,7 +131,7 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     mp_per_step = world * rows * W / 1e6
     value = mp_per_step * args.steps / dt
-    bpp = BYTES_PER_PX[args.workload]
+    bpp = BYTES_PER_PX[args.workload] if args.out == "rgba" else 2 + out_bpp
     timed_rows = dev.parts[0][1] if args.workload == "develop" else rows   # the launch the events bracket
     achieved = bpp * timed_rows * W / (kern_avg_ms * 1e-3) / 1e9   # GB/s, algorithmic bytes of ONE launch
 
@@ -142,7 +146,7 @@ def main():
                          f"data ({args.data}), frame {W}x{frame_h} in {world} row band(s)"
                          + (", 2-row halo exchange per step" + ("" if args.no_overlap else
                             " hidden behind the interior rows (edge rows launched after it)") if world > 1 else "")),
-            "variant": args.variant, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
+            "variant": args.variant, "out": args.out, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
             "kernel_ms_min": round(kern_ms[0], 4),
         },
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
