@@ -36,16 +36,20 @@ def exchange_halos(band, rank: int, world: int, group=None) -> None:
 
     if world == 1:
         return
+    import torch
+
     rows = band.shape[0] - 2 * HALO
     if rows < HALO:
         raise ValueError("a band must have at least 2 rows to feed its neighbours' halos")
+    # RCCL/NCCL has no 16-bit integer datatype: ship the rows as bytes (views, no copies)
+    raw = band.view(torch.uint8) if band.dtype != torch.uint8 else band
     ops = []
     if rank > 0:  # neighbour above: my first two rows are its bottom halo
-        ops.append(dist.P2POp(dist.isend, band[HALO:2 * HALO], rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, band[0:HALO], rank - 1, group))
+        ops.append(dist.P2POp(dist.isend, raw[HALO:2 * HALO], rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, raw[0:HALO], rank - 1, group))
     if rank < world - 1:  # neighbour below
-        ops.append(dist.P2POp(dist.isend, band[rows:rows + HALO], rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, band[rows + HALO:rows + 2 * HALO], rank + 1, group))
+        ops.append(dist.P2POp(dist.isend, raw[rows:rows + HALO], rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, raw[rows + HALO:rows + 2 * HALO], rank + 1, group))
     for req in dist.batch_isend_irecv(ops):
         req.wait()
 
