@@ -50,3 +50,10 @@ def test_tone_corner_values():
                dict(shadow=100, highlight=-100), dict(black=100, white=-100), dict(black=-100, white=100),
                dict(wb_temperature=100, wb_tint=100), dict(wb_temperature=-100, wb_tint=-100)):
         _check([O.EditParameters(**kw)], n=50_000, seed=9)
+
+
+def test_random_parameter_space():
+    rng = np.random.default_rng(2026)
+    for _ in range(30):
+        n_masks = int(rng.integers(1, 4))
+        _check([util.random_params(rng) for _ in range(n_masks)], n=20_000, seed=int(rng.integers(1 << 30)))

@@ -130,3 +130,33 @@ def configure_editor(ed, p: O.EditParameters, mask_name=None, main=True):
 def to_raw(rp: O.RawParams):
     import rawphotoforge_amd as R
     return R.RawParams(rp.cfa_pattern, rp.black, rp.white, rp.wb, rp.cam2rgb)
+
+
+def random_params(rng, trivial_prob=0.4) -> O.EditParameters:
+    """A random point of the operator's parameter space, including the flag combinations the kernels
+    specialise on (identity / constant curves, zero sliders)."""
+    def slider():
+        return 0 if rng.random() < trivial_prob else int(rng.integers(-100, 101))
+    p = O.EditParameters(exposure=0.0 if rng.random() < trivial_prob else float(np.float32(rng.uniform(-3, 3))),
+                         contrast=slider(), shadow=slider(), highlight=slider(), black=slider(), white=slider(),
+                         wb_temperature=slider(), wb_tint=slider())
+
+    def curve(kind):
+        u = rng.random()
+        if u < trivial_prob:
+            return None
+        if u < 0.6:   # PCHIP through random control points
+            n = int(rng.integers(2, 7))
+            xs = np.sort(rng.choice(65536, n, replace=False)).astype(np.int32)
+            xs[0], xs[-1] = 0, 65535
+            xs = np.unique(xs)
+            ys = rng.integers(0, 65536, xs.size).astype(np.int32)
+            return O.curve_from_control_points(xs, ys)
+        if u < 0.8:
+            return np.full(65536, int(rng.integers(0, 65536)), np.int32)
+        return rng.integers(-2000, 70000, 65536).astype(np.int32)   # arbitrary, incl. out-of-range entries
+    for name in ("brightness", "hue", "saturation", "lightness"):
+        c = curve(name)
+        if c is not None:
+            setattr(p, name + "_tone_curve", c)
+    return p
