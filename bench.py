@@ -174,11 +174,12 @@ def main():
         # all host threads; as many whole frames as fit in ~args.cpu_seconds of wall time (>= 1)
         cores = O.max_threads()
         O.develop(cfa, raw, [p], y0=0, rows=64)            # warm the library / thread pool
+        host_out = np.zeros((H, W, 4), np.float32)          # allocated and touched once, like the GPU's output
         times = []
         t_end = time.perf_counter() + args.cpu_seconds
         while not times or (time.perf_counter() < t_end and len(times) < 20):
             t1 = time.perf_counter()
-            O.develop(cfa, raw, [p])
+            O.develop(cfa, raw, [p], out=host_out)
             times.append(time.perf_counter() - t1)
         ct = sorted(times)[len(times) // 2]
         # the same frame on ONE thread, on a bounded band, for the per-core figure

@@ -215,13 +215,15 @@ def demosaic(cfa, raw: RawParams, y0=0, rows=None) -> np.ndarray:
     return out
 
 
-def develop(cfa, raw: RawParams, masks_params, masks=None, y0=0, rows=None) -> np.ndarray:
-    """Full RAW -> display chain: demosaic then apply."""
+def develop(cfa, raw: RawParams, masks_params, masks=None, y0=0, rows=None, out=None) -> np.ndarray:
+    """Full RAW -> display chain: demosaic then apply.  `out`: optional preallocated (rows, W, 4) f32."""
     c = np.ascontiguousarray(cfa, np.uint16)
     h, w = c.shape
     rows = h - y0 if rows is None else rows
     gp, luts = _pack(masks_params)
-    out = np.empty((rows, w, 4), np.float32)
+    if out is None:
+        out = np.empty((rows, w, 4), np.float32)
+    assert out.shape == (rows, w, 4) and out.dtype == np.float32 and out.flags.c_contiguous
     rp = raw.to_c()
     mptr = None
     if masks is not None:
