@@ -171,8 +171,16 @@ def main():
         import oracle as O   # the checker, timed as the reported CPU baseline (never on the GPU path)
         from tests import util
         raw, p = util.raw_params(), util.oracle_params(spec)
-        # all host threads; as many whole frames as fit in ~args.cpu_seconds of wall time (>= 1)
-        cores = O.max_threads()
+        # every host core this process may use (the box shares its CPUs by cgroup quota, which OpenMP does
+        # not see); as many whole frames as fit in ~args.cpu_seconds of wall time (>= 1)
+        cores = min(O.max_threads(), len(os.sched_getaffinity(0)))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                cores = max(1, min(cores, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+        O.set_threads(cores)
         O.develop(cfa, raw, [p], y0=0, rows=64)            # warm the library / thread pool
         host_out = np.zeros((H, W, 4), np.float32)          # allocated and touched once, like the GPU's output
         times = []
