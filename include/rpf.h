@@ -163,6 +163,12 @@ int rpf_set_mask_range(rpf_editor* e, float mask_range); /* EditParameters.mask_
 int rpf_reset(rpf_editor* e);
 int rpf_num_masks(const rpf_editor* e, uint32_t* n);
 
+/* Preview pyramid (web/main.ts:652-695): a new editor over the source editor's ORIGINAL image resized so that its
+ * long edge is target_long_edge, with the bilinear arithmetic of resizeFloat32RGBLongEdge (web/main.ts:958-1026),
+ * done on the device (the reference reads the frame back, resizes on the CPU and uploads again). */
+int rpf_preview_size(uint32_t src_width, uint32_t src_height, uint32_t target_long_edge, uint32_t* width, uint32_t* height);
+int rpf_editor_create_preview(rpf_editor* src, uint32_t target_long_edge, rpf_editor** out);
+
 int rpf_apply_adjustments(rpf_editor* e);
 int rpf_editor_sync(rpf_editor* e);
 

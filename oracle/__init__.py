@@ -314,3 +314,21 @@ def legacy_tone_lut(exposure=0.0, contrast=0, shadow=0, highlight=0, black=0, wh
     lib().orc_legacy_tone_lut(C.c_double(exposure), C.c_int(contrast), C.c_int(shadow), C.c_int(highlight),
                               C.c_int(black), C.c_int(white), _p(out, C.c_float))
     return out
+
+
+def preview_size(sw: int, sh: int, target: int):
+    """web/main.ts:971-977 -> (dst_width, dst_height)."""
+    dw, dh = C.c_uint32(), C.c_uint32()
+    lib().orc_preview_size(C.c_uint32(sw), C.c_uint32(sh), C.c_uint32(target), C.byref(dw), C.byref(dh))
+    return dw.value, dh.value
+
+
+def resize_long_edge(img, target: int) -> np.ndarray:
+    """web/main.ts:958-1026 resizeFloat32RGBLongEdge on an (H, W, 3|4) f32 image."""
+    a = np.ascontiguousarray(img, np.float32)
+    sh, sw, nch = a.shape
+    dw, dh = preview_size(sw, sh, target)
+    out = np.empty((dh, dw, nch), np.float32)
+    lib().orc_resize_bilinear(_p(a, C.c_float), C.c_uint32(sw), C.c_uint32(sh), C.c_uint32(nch), _p(out, C.c_float),
+                              C.c_uint32(dw), C.c_uint32(dh))
+    return out

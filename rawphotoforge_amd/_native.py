@@ -86,6 +86,8 @@ SYMBOLS = {
     "rpf_set_mask_range": (C.c_int, [_vp, C.c_float]),
     "rpf_reset": (C.c_int, [_vp]),
     "rpf_num_masks": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "rpf_preview_size": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
+    "rpf_editor_create_preview": (C.c_int, [_vp, C.c_uint32, _P(_vp)]),
     "rpf_apply_adjustments": (C.c_int, [_vp]),
     "rpf_editor_sync": (C.c_int, [_vp]),
     "rpf_get_rgba_f32": (C.c_int, [_vp, _f32p]),

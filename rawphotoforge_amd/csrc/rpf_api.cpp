@@ -464,6 +464,47 @@ int rpf_pchip_interpolate_i32(const int32_t* x_pts, size_t n_x, const int32_t* y
     return st ? ok() : fail(st);
 }
 
+// ---- preview pyramid (web/main.ts:652-695, 958-1026) -----------------------------------------
+
+int rpf_preview_size(uint32_t src_width, uint32_t src_height, uint32_t target_long_edge, uint32_t* width, uint32_t* height)
+{
+    if (!width || !height || src_width == 0 || src_height == 0 || target_long_edge == 0)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "bad preview size arguments");
+    if (src_width >= src_height) {  // Math.round(x) == floor(x + 0.5) for x >= 0
+        *width = target_long_edge;
+        *height = (uint32_t)floor((double)src_height * ((double)target_long_edge / (double)src_width) + 0.5);
+    } else {
+        *height = target_long_edge;
+        *width = (uint32_t)floor((double)src_width * ((double)target_long_edge / (double)src_height) + 0.5);
+    }
+    return ok();
+}
+
+int rpf_editor_create_preview(rpf_editor* src, uint32_t target_long_edge, rpf_editor** out)
+{
+    if (!out) return fail(RPF_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    int rc = need_device(src);
+    if (rc) return rc;
+    if (!src->owns_image) return fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: tile editor has no image to resize");
+    uint32_t dw = 0, dh = 0;
+    if ((rc = rpf_preview_size(src->geom.width, src->geom.rows, target_long_edge, &dw, &dh))) return rc;
+    if (dw == 0 || dh == 0) return fail(RPF_ERR_INVALID_ARGUMENT, "preview would be empty");
+    HIP_TRY(hipSetDevice(src->proc->device));
+    if (src->is_bayer && (rc = ensure_linear(src))) return rc;  // the pyramid is built from the linear RGB frame
+    rpf_tile t{dw, dh, 0, dh};
+    rpf_editor* e = nullptr;
+    if ((rc = rpf_editor_create_for_tile(src->proc, &t, &e))) return rc;
+    hipError_t he = hipMalloc((void**)&e->d_original, (size_t)dw * dh * 4 * sizeof(float));
+    if (he == hipSuccess) he = launch_resize(src->d_original, src->geom.width, src->geom.rows, e->d_original, dw, dh, src->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(src->stream);
+    if (he != hipSuccess) { rpf_editor_destroy(e); return hip_fail(he, "preview resize"); }
+    e->original_valid = true;
+    e->owns_image = true;
+    *out = e;
+    return ok();
+}
+
 // ---- apply / readback -----------------------------------------------------------------------
 
 int rpf_apply_adjustments(rpf_editor* e)

@@ -466,6 +466,39 @@ __global__ __launch_bounds__(256) void k_pad_rgb(const float* in, size_t npix, f
 }
 
 // ---------------------------------------------------------------------------
+// k_resize — the preview pyramid's bilinear resize (web/main.ts:958-1026 resizeFloat32RGBLongEdge),
+// RGBA32F -> RGBA32F on the device, binary64 arithmetic in the JavaScript source order, one thread
+// per destination pixel.  Alpha is rewritten as 1.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(const float4* src, uint32_t sw, uint32_t sh, float4* dst, uint32_t dw,
+                                                uint32_t dh)
+{
+    const double scaleX = (double)sw / (double)dw, scaleY = (double)sh / (double)dh;
+    const size_t n = (size_t)dw * dh;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t y = (uint32_t)(i / dw), x = (uint32_t)(i - (size_t)y * dw);
+        const double sy = ((double)y + 0.5) * scaleY - 0.5;
+        const double sx = ((double)x + 0.5) * scaleX - 0.5;
+        const double fy = __builtin_floor(sy), fx = __builtin_floor(sx);
+        const int64_t y0 = fy > 0 ? (int64_t)fy : 0, x0 = fx > 0 ? (int64_t)fx : 0;
+        const int64_t y1 = y0 + 1 < (int64_t)sh - 1 ? y0 + 1 : (int64_t)sh - 1;
+        const int64_t x1 = x0 + 1 < (int64_t)sw - 1 ? x0 + 1 : (int64_t)sw - 1;
+        const double ty = sy - (double)y0, tx = sx - (double)x0;
+        const float4 p00 = src[(size_t)y0 * sw + x0], p10 = src[(size_t)y0 * sw + x1];
+        const float4 p01 = src[(size_t)y1 * sw + x0], p11 = src[(size_t)y1 * sw + x1];
+        const float c00[3] = {p00.x, p00.y, p00.z}, c10[3] = {p10.x, p10.y, p10.z};
+        const float c01[3] = {p01.x, p01.y, p01.z}, c11[3] = {p11.x, p11.y, p11.z};
+        float o[3];
+        for (int c = 0; c < 3; ++c) {
+            const double cx0 = (double)c00[c] * (1.0 - tx) + (double)c10[c] * tx;
+            const double cx1 = (double)c01[c] * (1.0 - tx) + (double)c11[c] * tx;
+            o[c] = (float)(cx0 * (1.0 - ty) + cx1 * ty);
+        }
+        dst[i] = make_float4(o[0], o[1], o[2], 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_unpack — packed RAW (10/12/14/16-bit, MSB-first bit stream) -> u16 CFA plane.  Integer, bit-exact.
 // One thread = 16 samples = 2*BITS bytes read as BITS/2 dwords and two 16-B stores; a group that is
 // ragged (row end) or unaligned goes sample by sample.
@@ -710,6 +743,16 @@ hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t wi
     case 16: hipLaunchKernelGGL(k_unpack<16>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_resize(const float* d_src, uint32_t sw, uint32_t sh, float* d_dst, uint32_t dw, uint32_t dh, hipStream_t s)
+{
+    if (!d_src || !d_dst || sw == 0 || sh == 0 || dw == 0 || dh == 0) return hipErrorInvalidValue;
+    const size_t n = (size_t)dw * dh;
+    const uint32_t grid = (uint32_t)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_resize, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(d_src), sw, sh,
+                       reinterpret_cast<float4*>(d_dst), dw, dh);
     return hipGetLastError();
 }
 

@@ -41,6 +41,8 @@ hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom&
 // packed RAW (MSB-first bit stream, 10/12/14/16 bits) -> u16 plane of pitch `width`
 hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows, uint32_t bits,
                          uint16_t* d_out, hipStream_t s);
+// bilinear resize of the preview pyramid (web/main.ts:958-1026), RGBA32F -> RGBA32F
+hipError_t launch_resize(const float* d_src, uint32_t sw, uint32_t sh, float* d_dst, uint32_t dw, uint32_t dh, hipStream_t s);
 // RGBA32F -> RGB f32 / RGB u8 repack (image.rs:202-277, 375-383)
 hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_format, hipStream_t s);
 // interleaved RGB f32 -> RGBA32F, alpha = 1 (image.rs:135-139)

@@ -229,6 +229,13 @@ class PhotoEditor:
         _check(N.lib().rpf_editor_create_for_tile(gpu_processor._h, C.byref(t), C.byref(h)))
         return cls(h, gpu_processor)
 
+    def create_preview(self, target_long_edge: int) -> "PhotoEditor":
+        """A new editor over this editor's original image resized to `target_long_edge` (web/main.ts:652-695,
+        resizeFloat32RGBLongEdge :958-1026), computed on the device."""
+        h = C.c_void_p()
+        _check(N.lib().rpf_editor_create_preview(self._h, int(target_long_edge), C.byref(h)))
+        return PhotoEditor(h, self._proc)
+
     # -- geometry -------------------------------------------------------------------------------
     @property
     def width(self) -> int:
