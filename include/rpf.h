@@ -56,7 +56,7 @@ extern "C" {
 #endif
 
 #define RPF_CURVE_RESOLUTION 65536 /* lib.rs:17 */
-#define RPF_MAX_MASKS 8            /* "main" + 7 user masks per editor */
+#define RPF_MAX_MASKS 16           /* "main" + 15 user masks per editor */
 
 typedef enum rpf_status {
     RPF_OK = 0,

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librpf_hip.so")
 
 CURVE_RESOLUTION = 65536
-MAX_MASKS = 8
+MAX_MASKS = 16
 
 # rpf_status
 OK = 0

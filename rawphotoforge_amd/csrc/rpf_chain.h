@@ -8,7 +8,7 @@
 
 namespace rpf {
 
-#define RPF_MAX_MASKS 8
+#define RPF_MAX_MASKS 16
 #define RPF_CURVE_RESOLUTION 65536  // lib.rs:17
 
 enum MaskFlags : uint32_t {

@@ -394,3 +394,27 @@ def test_random_parameter_space_on_gpu(gpu):
             util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
         ed.apply_adjustments()
         assert_parity(ed.rgba(), want)
+
+
+def test_sixteen_masks(gpu):
+    """RPF_MAX_MASKS masks (the reference has no limit; its UI uses a handful): every mask's curves and its
+    u8 plane are gathered from L2, only "main"'s brightness curve lives in LDS."""
+    rng = np.random.default_rng(16)
+    h, w = 40, 72
+    n = R.MAX_MASKS
+    cfa = util.bayer_natural(h, w, seed=16)
+    rp = util.raw_params()
+    params = [util.random_params(rng, trivial_prob=0.3) for _ in range(n)]
+    masks = np.ones((n, h, w), np.float32)
+    ed = bayer_editor(gpu, cfa, rp)
+    for m in range(1, n):
+        mm = (rng.random((h, w)) > 0.7).astype(np.float32)
+        masks[m] = mm
+        ed.add_mask(f"m{m}", mm * 2.0 - 0.5)      # binarised at add_mask: >= 0 -> 1
+        masks[m] = O.binarize_mask(mm * 2.0 - 0.5)
+    for m, p in enumerate(params):
+        util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), O.develop(cfa, rp, params, masks=masks))
+    with pytest.raises(R.TooManyMasks):
+        ed.add_mask("one too many", masks[1])
