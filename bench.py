@@ -164,6 +164,8 @@ def main():
             result["roofline"]["traffic"] = tr["traffic_bytes"]
             result["roofline"]["traffic_unit"] = "HBM bytes per launch (algorithmic: %d)" % (bpp * rows * W)
             result["roofline"]["traffic_source"] = tr["source"]
+            if "valu" in tr:   # the secondary ceiling SURVEY.md §8(d) asks to report when frac < 0.7
+                result["roofline"]["valu"] = tr["valu"]
     except (OSError, ValueError):
         pass
 

@@ -225,6 +225,17 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + (tid >> 6));
     const uint32_t nwaves = gridDim.x * (NT / 64);
 
+    // A strip starts on a multiple of 64 columns, so this lane's RGGB cell column — and with it the
+    // normalisation constants of its column for even / odd window positions — is the same for every item.
+    const int cx = (lane + a.raw.xo) & 1;
+    const int cyE = bp, cyO = bp ^ 1;
+    const float blkE = cyE ? (cx ? a.raw.black[3] : a.raw.black[2]) : (cx ? a.raw.black[1] : a.raw.black[0]);
+    const float rngE = cyE ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
+    const float sclE = cyE ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
+    const float blkO = cyO ? (cx ? a.raw.black[3] : a.raw.black[2]) : (cx ? a.raw.black[1] : a.raw.black[0]);
+    const float rngO = cyO ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
+    const float sclO = cyO ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
+
     // Every item (64 columns x 2*seg_pairs rows) costs the same number of instructions whatever the
     // image holds, so the items are dealt round-robin: wave-uniform loop, no queue.
     for (uint32_t item = wave; item < a.nitems; item += nwaves) {
@@ -239,16 +250,6 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
         int hx = lane < 2 ? xl - 2 : (lane >= 62 ? xl + 2 : xl);
         hx = reflect101(hx, W);
         hx = hx < 0 ? 0 : (hx > W - 1 ? W - 1 : hx);
-        const int cx = (xl + a.raw.xo) & 1;
-        // normalisation constants of this lane's column for even / odd window positions
-        const int cyE = bp, cyO = bp ^ 1;
-        const float blkE = cyE ? (cx ? a.raw.black[3] : a.raw.black[2]) : (cx ? a.raw.black[1] : a.raw.black[0]);
-        const float rngE = cyE ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
-        const float sclE = cyE ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
-        const float blkO = cyO ? (cx ? a.raw.black[3] : a.raw.black[2]) : (cx ? a.raw.black[1] : a.raw.black[0]);
-        const float rngO = cyO ? (cx ? a.raw.range[3] : a.raw.range[2]) : (cx ? a.raw.range[1] : a.raw.range[0]);
-        const float sclO = cyO ? (cx ? a.raw.scale[3] : a.raw.scale[2]) : (cx ? a.raw.scale[1] : a.raw.scale[0]);
-
         // Row addressing: lane j works out, once per item, the element offset of window row j of this
         // item (reflect-101 at the frame edge, clamp inside the band buffer); the loop then fetches the two
         // offsets it needs per step with v_readlane instead of redoing ~20 scalar operations per row on

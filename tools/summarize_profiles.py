@@ -88,6 +88,15 @@ def main():
                        f"{(2 * fetch + write) / alg:.3f}x if the read count were halved)")
             traffic[w] = {"fetch_bytes": fetch, "write_bytes": write, "traffic_bytes": fetch + write,
                           "algorithmic_bytes": alg, "source": f"profiles/{label}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+            if "SQ_INSTS_VALU" in a and dur:
+                avg_us = sum(dur) / len(dur)
+                traffic[w]["valu"] = {
+                    "wave_instructions_per_launch": a["SQ_INSTS_VALU"],
+                    "per_pixel": a["SQ_INSTS_VALU"] * 64 / (mp * 1e6),
+                    "kernel_us_under_pmc": avg_us,
+                    "ns_per_instruction_per_simd": avg_us * 1e3 * 1024 / a["SQ_INSTS_VALU"],
+                    "note": "gfx950 issues one f32 add/mul/fma per ~1.1 ns per SIMD and one f64 / cvt / cndmask / cmp "
+                            "per ~1.8 ns (profiles/*_microbench.txt): at this instruction count the kernel is VALU-bound"}
         lines += ["Derived:", ""] + [f"- {d}" for d in der] + [""]
 
     for name in ("bench_default.json", "bench_variants.log", "microbench.txt"):
