@@ -116,3 +116,27 @@ void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint3
     twin_edit_chain(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
 }
 }
+
+// ---- host state machine under sanitizers (tools/sanitize_cpu.sh) ---------------------------------
+extern "C" int twin_state_exercise(void)
+{
+    rpf::EditState st(7, 5);
+    int fails = 0;
+    fails += !st.set_whitebalance(500, -500, nullptr) || st.masks[0].params.wb_temperature != 100;
+    fails += !!st.set_whitebalance(1, 1, "nope");
+    fails += !st.set_tone(99.0f, 500, -500, 3, 4, 5, nullptr) || st.masks[0].params.exposure != 10.0f;
+    const int32_t xs[4] = {0, 100, 50000, 65535}, ys[4] = {0, 70000, -5, 65535}, bad[3] = {0, 5, 5};
+    fails += !st.set_curve(RPF_CURVE_HUE, nullptr, 0, xs, 4, ys, 4, nullptr);
+    fails += st.set_curve(RPF_CURVE_HUE, nullptr, 0, bad, 3, ys, 3, nullptr).code != RPF_ERR_INTERP_NOT_STRICTLY_INCREASING;
+    fails += st.set_curve(RPF_CURVE_HUE, nullptr, 0, xs, 4, ys, 3, nullptr).code != RPF_ERR_INTERP_MISMATCHED_LENGTHS;
+    fails += st.set_curve(RPF_CURVE_HUE, xs, 4, nullptr, 0, nullptr, 0, nullptr).code != RPF_ERR_INTERP_INVALID_CURVE_LENGTH;
+    fails += st.set_curve(RPF_CURVE_HUE, nullptr, 0, nullptr, 0, nullptr, 0, nullptr).code != RPF_ERR_INTERP_MISSING_CURVE_OR_CONTROL_POINTS;
+    std::vector<float> m(35, 0.5f);
+    for (int i = 0; i < RPF_MAX_MASKS - 1; ++i) fails += !st.add_mask(("m" + std::to_string(i)).c_str(), m.data());
+    fails += st.add_mask("overflow", m.data()).code != RPF_ERR_TOO_MANY_MASKS;
+    fails += !st.remove_mask("m3") || !st.remove_mask("main") || st.masks.size() != (size_t)RPF_MAX_MASKS - 1;
+    for (auto& mk : st.masks) (void)rpf::make_mask_params(mk.params);
+    st.reset();
+    fails += st.masks.size() != 1 || st.masks[0].params.wb_temperature != 0;
+    return fails;
+}
