@@ -418,3 +418,20 @@ def test_sixteen_masks(gpu):
     assert_parity(ed.rgba(), O.develop(cfa, rp, params, masks=masks))
     with pytest.raises(R.TooManyMasks):
         ed.add_mask("one too many", masks[1])
+
+
+def test_editors_share_a_processor_and_interleave(gpu):
+    """One GpuProcessor, several editors on their own streams (the reference's 3-editor preview pyramid,
+    Arc<GpuProcessor>, lib.rs:83): interleaved setters / applies / readbacks stay independent."""
+    rng = np.random.default_rng(99)
+    eds, wants = [], []
+    for i, (h, w) in enumerate(((40, 64), (33, 50), (64, 96))):
+        img = rng.random((h, w, 3), dtype=np.float32)
+        eds.append((R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w), np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)))
+    for rep in range(5):
+        params = [util.random_params(rng) for _ in eds]
+        for (ed, _), p in zip(eds, params):
+            util.configure_editor(ed, p)
+            ed.apply_adjustments()            # enqueue all three before reading any back
+        for (ed, rgba), p in zip(eds, params):
+            assert_parity(ed.rgba(), O.apply(rgba, [p]))
