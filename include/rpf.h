@@ -218,7 +218,9 @@ int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_fo
 /* An editor that owns edit state + device LUTs/masks for a row tile but no image. */
 int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_editor** out);
 
-/* Kernel variant selection for A/B measurements (bench.py --variant); 0 = default. */
+/* Kernel variant selection for A/B measurements (bench.py --variant); 0 = shipped configuration.
+ * fused develop: 1 = LDS-tile front end (first design), 2 = 512-thread workgroups, 3 = pixel pair sequentially;
+ * demosaic: 1 = LDS-tile front end, 3 = ordinary (not nontemporal) stores, 4 = 16-row items.  Same output bits. */
 int rpf_set_kernel_variant(rpf_processor* p, int variant);
 
 #ifdef __cplusplus

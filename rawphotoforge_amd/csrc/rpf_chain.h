@@ -81,23 +81,6 @@ RPF_HD float mhc_axis(float c, float along, float d, float same2, float other2)
     return ((((5.0f * c + 4.0f * along) - d) - same2) + 0.5f * other2) * 0.125f;
 }
 
-// cx, cy: RGGB cell position of the site.  Inputs are the six neighbourhood sums.
-RPF_HD void mhc_site(int cx, int cy, float c, float s1, float e1, float d, float v2, float h2,
-                     float& R, float& G, float& B)
-{
-    if (cx == cy) {
-        const float cross = mhc_cross(c, s1, e1, v2, h2);
-        const float diag = mhc_diag(c, d, v2, h2);
-        G = cross;
-        if (cx == 0) { R = c; B = diag; } else { B = c; R = diag; }
-    } else {
-        const float horiz = mhc_axis(c, e1, d, h2, v2);
-        const float vert = mhc_axis(c, s1, d, v2, h2);
-        G = c;
-        if (cy == 0) { R = horiz; B = vert; } else { B = horiz; R = vert; }
-    }
-}
-
 RPF_HD void cam_to_linear(const float* m, float R, float G, float B, float& r, float& g, float& b)
 {
     r = m[0] * R + m[1] * G + m[2] * B;
