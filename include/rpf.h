@@ -131,6 +131,12 @@ int rpf_editor_create_from_rgb_f32(rpf_processor* p, const float* rgb, uint32_t 
  * fused demosaic -> ... -> gamma kernel. */
 int rpf_editor_create_from_bayer_u16(rpf_processor* p, const uint16_t* cfa, uint32_t width, uint32_t height,
                                      const rpf_raw_params* raw, rpf_editor** out);
+/* 16-bit binary PPM ("P6\n<w> <h>\n65535\n" + big-endian RGB samples), the development front-end's test input
+ * (web-ts/core/image.ts:146-195 loadPpm): sample / 65535 -> f32, alpha 1, converted on the device.  Same header
+ * grammar as the reference (three newline-terminated lines, no comments); a magic other than P6, a maxval other
+ * than 65535, or fewer than width*height*6 payload bytes give RPF_ERR_FAILED_TO_READ_IMAGE. */
+int rpf_ppm16_parse_header(const uint8_t* file, size_t len, uint32_t* width, uint32_t* height, size_t* data_offset);
+int rpf_editor_create_from_ppm16(rpf_processor* p, const uint8_t* file, size_t len, rpf_editor** out);
 /* Operator state only (setters, curves, masks bookkeeping) with no device: for exercising the
  * state machine where no GPU exists.  apply / get_* fail with RPF_ERR_GPU_COMPUTE. */
 int rpf_editor_create_headless(uint32_t width, uint32_t height, rpf_editor** out);
@@ -204,6 +210,9 @@ typedef struct rpf_tile {
  * this step is inside rawler / LibRaw (rust-godot-legacy/photo-editor/src/image.rs:516-523). */
 int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows,
                          uint32_t bits, uint16_t* d_cfa_out, void* stream);
+/* npix big-endian 16-bit RGB triplets (2-byte aligned) -> RGBA32F, v / 65535, alpha 1 (image.ts:172-189) */
+int rpf_dev_rgb16be_to_rgba_f32(rpf_processor* p, const uint8_t* d_rgb16be, size_t npix, float* d_rgba_out,
+                                void* stream);
 /* black level -> WB -> 5x5 demosaic -> camera matrix; linear RGBA32F out */
 int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_params* raw, const rpf_tile* tile,
                      float* d_rgba_out, void* stream);

@@ -332,3 +332,23 @@ def resize_long_edge(img, target: int) -> np.ndarray:
     lib().orc_resize_bilinear(_p(a, C.c_float), C.c_uint32(sw), C.c_uint32(sh), C.c_uint32(nch), _p(out, C.c_float),
                               C.c_uint32(dw), C.c_uint32(dh))
     return out
+
+
+def ppm16_header(file_bytes):
+    """web-ts/core/image.ts:146-173 -> (status, width, height, data_offset); status 0 ok, 1 not P6, 2 size line,
+    3 maxval, 4 truncated."""
+    a = np.frombuffer(bytes(file_bytes), np.uint8)
+    w, h, off = C.c_uint32(), C.c_uint32(), C.c_size_t()
+    rc = lib().orc_ppm16_header(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.byref(w), C.byref(h), C.byref(off))
+    return rc, w.value, h.value, off.value
+
+
+def ppm16_load(file_bytes) -> np.ndarray:
+    """loadPpm: (H, W, 4) f32 image of a 16-bit P6 file."""
+    rc, w, h, off = ppm16_header(file_bytes)
+    if rc:
+        raise ValueError(f"ppm16 header status {rc}")
+    a = np.frombuffer(bytes(file_bytes), np.uint8)
+    out = np.empty((h, w, 4), np.float32)
+    lib().orc_rgb16be_to_rgba(C.c_void_p(a.ctypes.data + off), C.c_size_t(w * h), out.ctypes.data_as(C.c_void_p))
+    return out

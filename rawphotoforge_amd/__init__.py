@@ -9,7 +9,7 @@ from ._native import (CFA_BGGR, CFA_GBRG, CFA_GRBG, CFA_RGGB, CURVE_BRIGHTNESS, 
 from .editor import (EmptyControlPoints, FailedToReadImage, GpuComputeError, GpuInitializationError, GpuProcessor,
                      InterpolationError, InvalidArgument, InvalidCurveLength, MaskNotFound, MismatchedLengths,
                      MissingControlPoints, MissingCurveOrControlPoints, NotEnoughPoints, NotStrictlyIncreasing,
-                     PhotoEditor, PhotoEditorError, RawParams, TooManyMasks, dev_demosaic, dev_unpack_bayer,
-                     pchip_interpolate)
+                     PhotoEditor, PhotoEditorError, RawParams, TooManyMasks, dev_demosaic, dev_rgb16be_to_rgba_f32,
+                     dev_unpack_bayer, pchip_interpolate, ppm16_parse_header)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

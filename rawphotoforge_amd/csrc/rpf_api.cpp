@@ -331,6 +331,40 @@ int rpf_editor_create_from_rgb_f32(rpf_processor* p, const float* rgb, uint32_t 
     return ok();
 }
 
+int rpf_ppm16_parse_header(const uint8_t* file, size_t len, uint32_t* width, uint32_t* height, size_t* data_offset)
+{
+    if (!width || !height || !data_offset) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    const Status st = ppm16_parse_header(file, len, width, height, data_offset);
+    return st.code ? fail(st) : ok();
+}
+
+int rpf_editor_create_from_ppm16(rpf_processor* p, const uint8_t* file, size_t len, rpf_editor** out)
+{
+    if (!p || !out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    uint32_t width = 0, height = 0;
+    size_t off = 0;
+    const Status st = ppm16_parse_header(file, len, &width, &height, &off);
+    if (st.code) return fail(st);
+    rpf_tile t{width, height, 0, height};
+    rpf_editor* e = nullptr;
+    int rc = rpf_editor_create_for_tile(p, &t, &e);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    uint8_t* d_raw = nullptr;  // the payload lands at an aligned device address whatever the header length was
+    hipError_t he = hipMalloc((void**)&d_raw, npix * 6);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->d_original, npix * 4 * sizeof(float));
+    if (he == hipSuccess) he = hipMemcpy(d_raw, file + off, npix * 6, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = launch_rgb16be(d_raw, npix, e->d_original, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (d_raw) (void)hipFree(d_raw);
+    if (he != hipSuccess) { rpf_editor_destroy(e); return hip_fail(he, "upload PPM"); }
+    e->original_valid = true;
+    e->owns_image = true;
+    *out = e;
+    return ok();
+}
+
 int rpf_editor_create_from_bayer_u16(rpf_processor* p, const uint16_t* cfa, uint32_t width, uint32_t height,
                                      const rpf_raw_params* raw, rpf_editor** out)
 {
@@ -604,6 +638,15 @@ int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_s
     if (row_stride < ((size_t)width * bits + 7) / 8) return fail(RPF_ERR_INVALID_ARGUMENT, "row_stride shorter than a packed row");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(launch_unpack(d_packed, row_stride, width, rows, bits, d_cfa_out, (hipStream_t)stream));
+    return ok();
+}
+
+int rpf_dev_rgb16be_to_rgba_f32(rpf_processor* p, const uint8_t* d_rgb16be, size_t npix, float* d_rgba_out, void* stream)
+{
+    if (!p || !d_rgb16be || !d_rgba_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (reinterpret_cast<uintptr_t>(d_rgb16be) & 1) return fail(RPF_ERR_INVALID_ARGUMENT, "samples must be 2-byte aligned");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(launch_rgb16be(d_rgb16be, npix, d_rgba_out, (hipStream_t)stream));
     return ok();
 }
 

@@ -367,4 +367,53 @@ struct EditState {
     }
 };
 
+// 16-bit PPM header, web-ts/core/image.ts:146-170 (loadPpm): three lines, each ended by 0x0A and trimmed:
+// "P6", "<width> <height>" (split on a single space), "65535".  Number() semantics are narrowed to plain
+// unsigned decimal integers; anything else is a read failure instead of a NaN-sized image.
+inline Status ppm16_parse_header(const uint8_t* file, size_t len, uint32_t* width, uint32_t* height, size_t* data_offset)
+{
+    size_t off = 0;
+    auto read_line = [&](std::string& line) -> bool {
+        const size_t start = off;
+        while (off < len && file[off] != 0x0A) ++off;
+        if (off >= len) return false;  // the reference would scan past the buffer
+        line.assign(reinterpret_cast<const char*>(file) + start, off - start);
+        ++off;
+        const char* ws = " \t\r\n\v\f";
+        const size_t a = line.find_first_not_of(ws);
+        line = a == std::string::npos ? std::string() : line.substr(a, line.find_last_not_of(ws) - a + 1);
+        return true;
+    };
+    auto parse_uint = [](const std::string& t, uint32_t* v) -> bool {
+        if (t.empty() || t.size() > 9) return false;
+        uint32_t acc = 0;
+        for (char c : t) {
+            if (c < '0' || c > '9') return false;
+            acc = acc * 10 + (uint32_t)(c - '0');
+        }
+        *v = acc;
+        return true;
+    };
+    const Status bad_header{RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: truncated PPM header"};
+    std::string line;
+    if (!file || !read_line(line)) return bad_header;
+    if (line != "P6") return Status{RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: PPM format must be P6"};
+    if (!read_line(line)) return bad_header;
+    const size_t sp = line.find(' ');
+    uint32_t w = 0, h = 0;
+    if (sp == std::string::npos || !parse_uint(line.substr(0, sp), &w) || !parse_uint(line.substr(sp + 1), &h) || w == 0 ||
+        h == 0)
+        return Status{RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: PPM size line must be \"<width> <height>\""};
+    if (!read_line(line)) return bad_header;
+    uint32_t maxval = 0;
+    if (!parse_uint(line, &maxval) || maxval != 65535)
+        return Status{RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: Only 16bit PPM (max=65535) supported"};
+    if ((len - off) / 6 < (size_t)w * h)
+        return Status{RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: PPM payload shorter than width*height*6 bytes"};
+    *width = w;
+    *height = h;
+    *data_offset = off;
+    return Status{};
+}
+
 }  // namespace rpf

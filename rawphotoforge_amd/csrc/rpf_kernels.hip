@@ -466,6 +466,20 @@ __global__ __launch_bounds__(256) void k_pad_rgb(const float* in, size_t npix, f
         out[i] = make_float4(in[i * 3], in[i * 3 + 1], in[i * 3 + 2], 1.0f);
 }
 
+// 16-bit PPM payload -> RGBA32F (web-ts/core/image.ts:172-189): big-endian samples, v / 65535 (binary64 in the
+// JavaScript, rounded once into the Float32Array: equal to the binary32 quotient for all 65536 values, checked in
+// tests/test_ppm.py), alpha 1.
+__global__ __launch_bounds__(256) void k_rgb16be(const uint16_t* in, size_t npix, float4* out)
+{
+    const float inv = (float)(1.0 / 65535.0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const uint32_t r = __builtin_bswap16(in[i * 3]), g = __builtin_bswap16(in[i * 3 + 1]),
+                       b = __builtin_bswap16(in[i * 3 + 2]);
+        out[i] = make_float4(div_u16_by(r, 65535.0f, inv), div_u16_by(g, 65535.0f, inv), div_u16_by(b, 65535.0f, inv),
+                             1.0f);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_resize — the preview pyramid's bilinear resize (web/main.ts:958-1026 resizeFloat32RGBLongEdge),
 // RGBA32F -> RGBA32F on the device, binary64 arithmetic in the JavaScript source order, one thread
@@ -779,6 +793,16 @@ hipError_t launch_pad_rgb(const float* d_rgb, size_t npix, float* d_rgba, hipStr
     if (!d_rgb || !d_rgba) return hipErrorInvalidValue;
     const uint32_t grid = (uint32_t)((npix + 255) / 256 > 4096 ? 4096 : (npix + 255) / 256);
     hipLaunchKernelGGL(k_pad_rgb, dim3(grid), dim3(256), 0, s, d_rgb, npix, reinterpret_cast<float4*>(d_rgba));
+    return hipGetLastError();
+}
+
+hipError_t launch_rgb16be(const uint8_t* d_in, size_t npix, float* d_rgba, hipStream_t s)
+{
+    if (npix == 0) return hipSuccess;
+    if (!d_in || !d_rgba || (reinterpret_cast<uintptr_t>(d_in) & 1)) return hipErrorInvalidValue;
+    const uint32_t grid = (uint32_t)((npix + 255) / 256 > 8192 ? 8192 : (npix + 255) / 256);
+    hipLaunchKernelGGL(k_rgb16be, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(d_in), npix,
+                       reinterpret_cast<float4*>(d_rgba));
     return hipGetLastError();
 }
 

@@ -47,5 +47,6 @@ hipError_t launch_resize(const float* d_src, uint32_t sw, uint32_t sh, float* d_
 hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_format, hipStream_t s);
 // interleaved RGB f32 -> RGBA32F, alpha = 1 (image.rs:135-139)
 hipError_t launch_pad_rgb(const float* d_rgb, size_t npix, float* d_rgba, hipStream_t s);
+hipError_t launch_rgb16be(const uint8_t* d_in, size_t npix, float* d_rgba, hipStream_t s);
 
 }  // namespace rpf

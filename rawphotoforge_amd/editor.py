@@ -202,6 +202,14 @@ class PhotoEditor:
         return cls(h, gpu_processor)
 
     @classmethod
+    def new_from_ppm16(cls, gpu_processor: GpuProcessor, file_bytes) -> "PhotoEditor":
+        """A 16-bit P6 PPM file (web-ts/core/image.ts:146-195 loadPpm); samples become f32 on the device."""
+        a = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
+        h = C.c_void_p()
+        _check(N.lib().rpf_editor_create_from_ppm16(gpu_processor._h, _ptr(a, C.c_uint8), a.size, C.byref(h)))
+        return cls(h, gpu_processor)
+
+    @classmethod
     def new_from_bayer_u16(cls, gpu_processor: GpuProcessor, cfa, raw: RawParams) -> "PhotoEditor":
         """RAW ingest (the step the Godot-legacy crate hands to rawler, image.rs:509-557)."""
         a = np.ascontiguousarray(cfa, dtype=np.uint16)
@@ -371,6 +379,20 @@ def dev_demosaic(processor: GpuProcessor, d_cfa_ptr: int, raw: RawParams, frame_
     t = N.Tile(frame_width, frame_height, y0, rows)
     _check(N.lib().rpf_dev_demosaic(processor._h, C.c_void_p(d_cfa_ptr), C.byref(rp), C.byref(t),
                                     C.c_void_p(d_rgba_ptr), C.c_void_p(stream)))
+
+
+def ppm16_parse_header(file_bytes):
+    """(width, height, data_offset) of a 16-bit P6 PPM, with loadPpm's header grammar (image.ts:146-170)."""
+    a = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
+    w, h, off = C.c_uint32(), C.c_uint32(), C.c_size_t()
+    _check(N.lib().rpf_ppm16_parse_header(_ptr(a, C.c_uint8), a.size, C.byref(w), C.byref(h), C.byref(off)))
+    return w.value, h.value, off.value
+
+
+def dev_rgb16be_to_rgba_f32(processor: GpuProcessor, d_samples_ptr: int, npix: int, d_rgba_ptr: int, stream: int = 0) -> None:
+    """Big-endian u16 RGB triplets -> RGBA32F (v / 65535, alpha 1) on the device."""
+    _check(N.lib().rpf_dev_rgb16be_to_rgba_f32(processor._h, C.c_void_p(d_samples_ptr), npix, C.c_void_p(d_rgba_ptr),
+                                               C.c_void_p(stream)))
 
 
 def dev_unpack_bayer(processor: GpuProcessor, d_packed_ptr: int, row_stride: int, width: int, rows: int, bits: int,
