@@ -36,6 +36,28 @@ static int hip_fail(hipError_t e, const char* what, int code = RPF_ERR_GPU_COMPU
                                                                       : "GPU compute error: ") +
                           what + ": " + hipGetErrorString(e));
 }
+// No C++ exception may cross the C boundary: host-side state (curves, masks, strings) allocates.
+static int fail_exception() noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        try { g_last_error = "out of host memory"; } catch (...) {}
+        return RPF_ERR_INVALID_ARGUMENT;
+    } catch (const std::exception& ex) {
+        try { g_last_error = std::string("internal error: ") + ex.what(); } catch (...) {}
+        return RPF_ERR_GPU_COMPUTE;
+    } catch (...) {
+        return RPF_ERR_GPU_COMPUTE;
+    }
+}
+#define RPF_GUARDED(...)   \
+    try {                  \
+        __VA_ARGS__        \
+    } catch (...) {        \
+        return fail_exception(); \
+    }
+
 #define HIP_TRY(expr)                                        \
     do {                                                     \
         hipError_t _e = (expr);                              \
@@ -82,7 +104,12 @@ static LaunchCfg cfg_of(const rpf_processor* p) { return LaunchCfg{p->num_cus, p
 static size_t npix_of(const rpf_editor* e) { return (size_t)e->geom.rows * e->geom.width; }
 
 // Refresh the device copy of params / curves / masks if a setter ran since the last upload.
+static int sync_edit_state_impl(rpf_editor* e);
 static int sync_edit_state(rpf_editor* e)
+{
+    RPF_GUARDED(return sync_edit_state_impl(e);)
+}
+static int sync_edit_state_impl(rpf_editor* e)
 {
     const uint32_t n = (uint32_t)e->state.masks.size();
     if (e->uploaded_params != e->state.params_version) {
@@ -280,11 +307,11 @@ int rpf_editor_create_headless(uint32_t width, uint32_t height, rpf_editor** out
 {
     if (!out) return fail(RPF_ERR_INVALID_ARGUMENT, "null out");
     *out = nullptr;
-    rpf_editor* e = new (std::nothrow) rpf_editor(width, height);
-    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "out of host memory");
-    e->geom = TileGeom{width, height, 0, height};
-    *out = e;
-    return ok();
+    RPF_GUARDED(
+        rpf_editor* e = new rpf_editor(width, height);
+        e->geom = TileGeom{width, height, 0, height};
+        *out = e;
+        return ok();)
 }
 
 int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_editor** out)
@@ -294,13 +321,13 @@ int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_edito
     if (tile->frame_width == 0 || tile->rows == 0 || (uint64_t)tile->y0 + tile->rows > tile->frame_height)
         return fail(RPF_ERR_INVALID_ARGUMENT, "tile outside its frame");
     // masks and the state machine are tile-sized: rows x frame_width
-    std::unique_ptr<rpf_editor> e(new (std::nothrow) rpf_editor(tile->frame_width, tile->rows));
-    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "out of host memory");
-    e->geom = TileGeom{tile->frame_width, tile->frame_height, tile->y0, tile->rows};
-    int rc = editor_device_init(e.get(), p);
-    if (rc) { rpf_editor_destroy(e.release()); return rc; }
-    *out = e.release();
-    return ok();
+    RPF_GUARDED(
+        std::unique_ptr<rpf_editor> e(new rpf_editor(tile->frame_width, tile->rows));
+        e->geom = TileGeom{tile->frame_width, tile->frame_height, tile->y0, tile->rows};
+        int rc = editor_device_init(e.get(), p);
+        if (rc) { rpf_editor_destroy(e.release()); return rc; }
+        *out = e.release();
+        return ok();)
 }
 
 int rpf_editor_create_from_rgb_f32(rpf_processor* p, const float* rgb, uint32_t width, uint32_t height,
@@ -334,8 +361,8 @@ int rpf_editor_create_from_rgb_f32(rpf_processor* p, const float* rgb, uint32_t 
 int rpf_ppm16_parse_header(const uint8_t* file, size_t len, uint32_t* width, uint32_t* height, size_t* data_offset)
 {
     if (!width || !height || !data_offset) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
-    const Status st = ppm16_parse_header(file, len, width, height, data_offset);
-    return st.code ? fail(st) : ok();
+    RPF_GUARDED(const Status st = ppm16_parse_header(file, len, width, height, data_offset);
+                return st.code ? fail(st) : ok();)
 }
 
 int rpf_editor_create_from_ppm16(rpf_processor* p, const uint8_t* file, size_t len, rpf_editor** out)
@@ -344,8 +371,7 @@ int rpf_editor_create_from_ppm16(rpf_processor* p, const uint8_t* file, size_t l
     *out = nullptr;
     uint32_t width = 0, height = 0;
     size_t off = 0;
-    const Status st = ppm16_parse_header(file, len, &width, &height, &off);
-    if (st.code) return fail(st);
+    if (int rc = rpf_ppm16_parse_header(file, len, &width, &height, &off)) return rc;
     rpf_tile t{width, height, 0, height};
     rpf_editor* e = nullptr;
     int rc = rpf_editor_create_for_tile(p, &t, &e);
@@ -409,8 +435,7 @@ int rpf_height(const rpf_editor* e, uint32_t* height)
 #define STATE_CALL(expr)                                   \
     do {                                                   \
         if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor"); \
-        Status _st = (expr);                               \
-        return _st ? ok() : fail(_st);                     \
+        RPF_GUARDED(Status _st = (expr); return _st ? ok() : fail(_st);) \
     } while (0)
 
 int rpf_set_whitebalance(rpf_editor* e, int32_t temperature, int32_t tint, const char* mask_name)
@@ -457,7 +482,7 @@ int rpf_set_mask_range(rpf_editor* e, float mask_range)
 int rpf_reset(rpf_editor* e)
 {
     if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor");
-    e->state.reset();
+    RPF_GUARDED(e->state.reset();)
     e->image_valid = false;  // lib.rs:228: image = original_image.clone()
     return ok();
 }
@@ -472,21 +497,23 @@ int rpf_num_masks(const rpf_editor* e, uint32_t* n)
 int rpf_editor_get_gpu_params(const rpf_editor* e, const char* mask_name, rpf_gpu_edit_parameters* out)
 {
     if (!e || !out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
-    Status st;
-    const EditParameters* p = e->state.find(mask_name, st);
-    if (!p) return fail(st);
-    *out = convert_params(*p);
-    return ok();
+    RPF_GUARDED(
+        Status st;
+        const EditParameters* p = e->state.find(mask_name, st);
+        if (!p) return fail(st);
+        *out = convert_params(*p);
+        return ok();)
 }
 
 int rpf_editor_get_curve(const rpf_editor* e, int which, const char* mask_name, int32_t* out65536)
 {
     if (!e || !out65536 || which < 0 || which > 3) return fail(RPF_ERR_INVALID_ARGUMENT, "bad argument");
-    Status st;
-    const EditParameters* p = e->state.find(mask_name, st);
-    if (!p) return fail(st);
-    memcpy(out65536, p->curve[which].data(), sizeof(int32_t) * RPF_CURVE_RESOLUTION);
-    return ok();
+    RPF_GUARDED(
+        Status st;
+        const EditParameters* p = e->state.find(mask_name, st);
+        if (!p) return fail(st);
+        memcpy(out65536, p->curve[which].data(), sizeof(int32_t) * RPF_CURVE_RESOLUTION);
+        return ok();)
 }
 
 int rpf_pchip_interpolate_i32(const int32_t* x_pts, size_t n_x, const int32_t* y_pts, size_t n_y,
@@ -494,8 +521,8 @@ int rpf_pchip_interpolate_i32(const int32_t* x_pts, size_t n_x, const int32_t* y
 {
     if ((n_x && !x_pts) || (n_y && !y_pts) || (n_eval && (!x_eval || !y_eval)))
         return fail(RPF_ERR_INVALID_ARGUMENT, "null array");
-    Status st = pchip_interpolate_i32(x_pts, n_x, y_pts, n_y, x_eval, n_eval, y_eval, bad_index);
-    return st ? ok() : fail(st);
+    RPF_GUARDED(Status st = pchip_interpolate_i32(x_pts, n_x, y_pts, n_y, x_eval, n_eval, y_eval, bad_index);
+                return st ? ok() : fail(st);)
 }
 
 // ---- preview pyramid (web/main.ts:652-695, 958-1026) -----------------------------------------
