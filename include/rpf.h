@@ -175,6 +175,14 @@ int rpf_num_masks(const rpf_editor* e, uint32_t* n);
 int rpf_preview_size(uint32_t src_width, uint32_t src_height, uint32_t target_long_edge, uint32_t* width, uint32_t* height);
 int rpf_editor_create_preview(rpf_editor* src, uint32_t target_long_edge, rpf_editor** out);
 
+/* Which of the reference's two shader generations apply runs.  ACTIVE = rust/photo-editor/src/wgpu_shader.wgsl.
+ * GODOT_LEGACY = rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl: the stored image is sRGB-encoded and is
+ * linearised on the sampled input (:89-97, :281-283), and the vignette uses coordinates * 2.0, falloff exponent 4.0
+ * and a [0, 2] gain clamp (:173-186).  Everything else is identical.  A Bayer editor's frame is linear already, so
+ * for it only the vignette changes (and apply takes the two-pass route: the fused kernel is the active shader). */
+enum { RPF_FLAVOUR_ACTIVE = 0, RPF_FLAVOUR_GODOT_LEGACY = 1 };
+int rpf_set_shader_flavour(rpf_editor* e, int flavour);
+
 int rpf_apply_adjustments(rpf_editor* e);
 int rpf_editor_sync(rpf_editor* e);
 

@@ -179,12 +179,14 @@ def _pack(masks_params):
     return gp, luts
 
 
-def apply(image_rgba, masks_params, masks=None, frame_hw=None, y0=0) -> np.ndarray:
+def apply(image_rgba, masks_params, masks=None, frame_hw=None, y0=0, legacy=None) -> np.ndarray:
     """GpuProcessor::apply_adjustments + wgsl main (gpu_image_processing.rs:214-400).
 
     image_rgba : (rows, W, 4) f32 tile.  masks_params : list[EditParameters], [0] is "main".
     masks : None (every mask all-ones) or (N, rows, W) f32, already binarised.
     frame_hw : (H, W) of the full frame when image_rgba is a row tile starting at y0.
+    legacy : None = the active shader; "encoded" = the Godot-legacy shader (sRGB-encoded input linearised, older
+             vignette; rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl); "linear" = its vignette only.
     """
     img = np.ascontiguousarray(image_rgba, np.float32)
     rows, w = img.shape[:2]
@@ -197,9 +199,12 @@ def apply(image_rgba, masks_params, masks=None, frame_hw=None, y0=0) -> np.ndarr
         mk = np.ascontiguousarray(masks, np.float32)
         assert mk.shape == (len(masks_params), rows, w)
         mptr = _p(mk, C.c_float)
-    lib().orc_apply(_p(img, C.c_float), C.c_uint32(fw), C.c_uint32(fh), C.c_uint32(y0), C.c_uint32(rows),
-                    mptr, C.c_uint32(len(masks_params)), gp, *[_p(l, C.c_int32) for l in luts],
-                    _p(out, C.c_float))
+    args = [_p(img, C.c_float), C.c_uint32(fw), C.c_uint32(fh), C.c_uint32(y0), C.c_uint32(rows),
+            mptr, C.c_uint32(len(masks_params)), gp, *[_p(l, C.c_int32) for l in luts], _p(out, C.c_float)]
+    if legacy is None:
+        lib().orc_apply(*args)
+    else:
+        lib().orc_apply_legacy(*args, C.c_int({"encoded": 1, "linear": 0}[legacy]))
     return out
 
 

@@ -13,7 +13,10 @@
 #include "rpf_host.h"
 #include "rpf_launch.h"
 
-namespace rpf { void build_math_tables(MathTables& T); }
+namespace rpf {
+void build_math_tables(MathTables& T);
+void build_legacy_tables(LegacyTables& T);
+}
 
 using namespace rpf;
 
@@ -69,6 +72,7 @@ struct rpf_processor {
     int num_cus = 0;
     int variant = 0;
     MathTables* d_tabs = nullptr;
+    LegacyTables* d_legacy = nullptr;  // Godot-legacy flavour only
     std::atomic<int> editors{0};
 };
 
@@ -78,6 +82,7 @@ struct rpf_editor {
     TileGeom geom{};
     bool owns_image = false;      // created from host pixels (vs. for_tile)
     bool is_bayer = false;
+    int flavour = RPF_FLAVOUR_ACTIVE;
     RawParamsDev raw{};
     uint16_t* d_cfa = nullptr;    // (rows + 4) x width, rows 0,1 and rows+2,rows+3 are halo
     float* d_original = nullptr;  // RGBA32F linear (rgb editors; bayer editors: demosaic cache)
@@ -146,6 +151,7 @@ static int sync_edit_state_impl(rpf_editor* e)
         e->dev.bright = e->d_bright;
         e->dev.hsl = e->d_hsl;
         e->dev.tabs = e->proc->d_tabs;
+        e->dev.legacy = e->proc->d_legacy;
         e->uploaded_params = e->state.params_version;
     }
     if (e->uploaded_masks != e->state.masks_version) {
@@ -165,6 +171,12 @@ static int sync_edit_state_impl(rpf_editor* e)
         e->uploaded_masks = e->state.masks_version;
     }
     return ok();
+}
+
+static uint32_t flavour_flags(const rpf_editor* e)
+{
+    if (e->flavour != RPF_FLAVOUR_GODOT_LEGACY) return 0u;
+    return EF_LEGACY_VIGNETTE | (e->is_bayer ? 0u : EF_DECODE_INPUT);
 }
 
 static int need_device(const rpf_editor* e)
@@ -246,6 +258,15 @@ int rpf_processor_create(int device, rpf_processor** out)
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(tables)", RPF_ERR_GPU_INITIALIZATION);
     e = hipMemcpy(p->d_tabs, tabs.get(), sizeof(MathTables), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(p->d_tabs); return hip_fail(e, "hipMemcpy(tables)", RPF_ERR_GPU_INITIALIZATION); }
+    std::unique_ptr<LegacyTables> legacy(new LegacyTables);
+    build_legacy_tables(*legacy);
+    e = hipMalloc((void**)&p->d_legacy, sizeof(LegacyTables));
+    if (e == hipSuccess) e = hipMemcpy(p->d_legacy, legacy.get(), sizeof(LegacyTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(p->d_tabs);
+        if (p->d_legacy) (void)hipFree(p->d_legacy);
+        return hip_fail(e, "legacy tables", RPF_ERR_GPU_INITIALIZATION);
+    }
     *out = p.release();
     return ok();
 }
@@ -253,7 +274,10 @@ int rpf_processor_create(int device, rpf_processor** out)
 void rpf_processor_destroy(rpf_processor* p)
 {
     if (!p) return;
-    if (hipSetDevice(p->device) == hipSuccess && p->d_tabs) (void)hipFree(p->d_tabs);
+    if (hipSetDevice(p->device) == hipSuccess) {
+        if (p->d_tabs) (void)hipFree(p->d_tabs);
+        if (p->d_legacy) (void)hipFree(p->d_legacy);
+    }
     delete p;
 }
 
@@ -479,6 +503,15 @@ int rpf_set_mask_range(rpf_editor* e, float mask_range)
     return ok();
 }
 
+int rpf_set_shader_flavour(rpf_editor* e, int flavour)
+{
+    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor");
+    if (flavour != RPF_FLAVOUR_ACTIVE && flavour != RPF_FLAVOUR_GODOT_LEGACY)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "unknown shader flavour");
+    e->flavour = flavour;
+    return ok();
+}
+
 int rpf_reset(rpf_editor* e)
 {
     if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor");
@@ -577,7 +610,11 @@ int rpf_apply_adjustments(rpf_editor* e)
     if ((rc = sync_edit_state(e))) return rc;
     if ((rc = ensure_image_buffer(e))) return rc;
     const LaunchCfg cfg = cfg_of(e->proc);
-    if (e->is_bayer && e->dev.lens_strength == 0.0f) {
+    // Godot-legacy flavour: its vignette, and — for images that were handed over sRGB-encoded, which is how that
+    // crate stores them (rust-godot-legacy/photo-editor/src/image.rs) — srgb_to_linear on the sampled input.
+    // A Bayer editor's frame is linear already (the legacy crate let rawler encode it, then decoded it here).
+    e->dev.flags = flavour_flags(e);
+    if (e->is_bayer && e->dev.lens_strength == 0.0f && e->dev.flags == 0) {
         HIP_TRY(launch_develop(cfg, e->d_cfa, e->raw, e->geom, e->dev, e->d_image, OUT_RGBA_F32, e->stream));
     } else {
         if (e->is_bayer && (rc = ensure_linear(e))) return rc;  // resampling needs the demosaiced frame
@@ -688,6 +725,10 @@ int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* 
     if (e->dev.lens_strength != 0.0f)
         return fail(RPF_ERR_INVALID_ARGUMENT,
                     "lens distortion resamples the whole frame: demosaic first, then rpf_dev_apply on the full frame");
+    if (e->flavour != RPF_FLAVOUR_ACTIVE)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only: use rpf_dev_demosaic, "
+                                              "then rpf_dev_apply, for the Godot-legacy flavour");
+    e->dev.flags = 0;
     HIP_TRY(launch_develop(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->dev, d_out, out_format,
                            (hipStream_t)stream));
     return ok();
@@ -702,6 +743,7 @@ int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_fo
     if ((rc = sync_edit_state(e))) return rc;
     if (e->dev.lens_strength != 0.0f && (e->geom.y0 != 0 || e->geom.rows != e->geom.height))
         return fail(RPF_ERR_INVALID_ARGUMENT, "lens distortion resamples the whole frame: the tile must be the frame");
+    e->dev.flags = flavour_flags(e);  // legacy: d_rgba_in is taken as sRGB-encoded, as that shader's input is
     HIP_TRY(launch_apply(cfg_of(e->proc), d_rgba_in, e->geom, e->dev, d_out, out_format, (hipStream_t)stream));
     return ok();
 }

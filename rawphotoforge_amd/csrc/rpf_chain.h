@@ -100,6 +100,25 @@ RPF_HD float vignette_gain(float vign_strength, int x, int y, float w, float h)
     return clampf(1.0f - (vign_strength * falloff), 0.0f, 4.0f);
 }
 
+// The Godot-legacy flavour of the same shader (rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl:173-186):
+// coordinates scaled by 2.0, falloff exponent 4.0, gain clamped to [0, 2].
+RPF_HD float vignette_gain_legacy(float vign_strength, int x, int y, float w, float h)
+{
+    const float cx = ((float)x / w - 0.5f) * 2.0f;
+    const float cy = ((float)y / h - 0.5f) * 2.0f;
+    const float dist = __builtin_sqrtf(cx * cx + cy * cy);
+    const float falloff = pow_4(clampf((dist - 0.25f) / 0.75f, 0.0f, 1.0f));
+    return clampf(1.0f - (vign_strength * falloff), 0.0f, 2.0f);
+}
+
+// Godot-legacy :89-97 srgb_to_linear, applied to the sampled input before everything else (:281-283)
+RPF_HD float srgb_to_linear1(float c, const PowTable& decode)
+{
+    const float lin = c / 12.92f;
+    const float p = powc<POW_DECODE>((c + 0.055f) / 1.055f, decode);
+    return c <= 0.04045f ? lin : p;
+}
+
 // ---------------------------------------------------------------------------
 // wgsl:109-164 lens_distortion_sample, strength != 0 branch.
 // fetch(x, y, rgb[3]) reads one RGBA32F texel of the whole frame.

@@ -435,8 +435,14 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
                 const float4 v = a.in[pix[k]];
                 r[k] = v.x; g[k] = v.y; b[k] = v.z;
             }
+            if (a.ed.flags & EF_DECODE_INPUT) {  // Godot-legacy :281-283: the stored image is sRGB-encoded
+                const PowTable& D = a.ed.legacy->decode;
+                r[k] = srgb_to_linear1(r[k], D); g[k] = srgb_to_linear1(g[k], D); b[k] = srgb_to_linear1(b[k], D);
+            }
             if (a.ed.vign_strength != 0.0f) {
-                const float gain = vignette_gain(a.ed.vign_strength, x, gy, (float)W, (float)H);
+                const float gain = (a.ed.flags & EF_LEGACY_VIGNETTE)
+                                       ? vignette_gain_legacy(a.ed.vign_strength, x, gy, (float)W, (float)H)
+                                       : vignette_gain(a.ed.vign_strength, x, gy, (float)W, (float)H);
                 r[k] *= gain; g[k] *= gain; b[k] *= gain;
             }
             active[k] = a.ed.num_masks > 1 ? active_masks(a.ed, pix[k], npix) : 1u;
@@ -688,6 +694,7 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
     if (e != hipSuccess) return e;
     if (!d_cfa || !d_out) return hipErrorInvalidValue;
     if (ed.lens_strength != 0.0f) return hipErrorInvalidValue;  // needs the resampling pass (launch_apply)
+    if (ed.flags != 0) return hipErrorInvalidValue;             // the Godot-legacy flavour lives in k_apply only
     switch (out_format) {
     case OUT_RGBA_F32: return develop_fmt<OUT_RGBA_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
     case OUT_RGB_F32: return develop_fmt<OUT_RGB_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
@@ -731,6 +738,7 @@ hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom&
     // the resampling branch reads anywhere in the frame: the tile must be the whole frame
     if (ed.lens_strength != 0.0f && (g.y0 != 0 || g.rows != g.height)) return hipErrorInvalidValue;
     if (ed.lens_strength != 0.0f && d_in == d_out) return hipErrorInvalidValue;
+    if ((ed.flags & EF_DECODE_INPUT) && !ed.legacy) return hipErrorInvalidValue;
     ApplyArgs a;
     memset(&a, 0, sizeof(a));
     a.in = reinterpret_cast<const float4*>(d_in); a.g = g; a.out = d_out; a.ed = ed;

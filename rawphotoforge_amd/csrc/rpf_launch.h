@@ -16,7 +16,11 @@ struct DeviceEdit {
     const MathTables* tabs;
     float vign_strength;         // (-vignette / 100) * 2, 0 = off       wgsl:167
     float lens_strength;         // -0.5 * (lens_distortion / 100), 0 = off   wgsl:110
+    // Godot-legacy shader flavour (k_apply only): EF_* bits, and the c = 2.4 table when EF_DECODE_INPUT is set
+    uint32_t flags;
+    const LegacyTables* legacy;
 };
+enum EditFlags : uint32_t { EF_LEGACY_VIGNETTE = 1u, EF_DECODE_INPUT = 2u };
 
 struct TileGeom {
     uint32_t width, height;  // full frame

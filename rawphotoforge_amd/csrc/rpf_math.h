@@ -50,7 +50,7 @@ struct MathTables {
 
 // binomial(c, k), k = 1..5, for the two exponents (tools/gen_math_consts.py); compile-time
 // constants so they live in SGPRs / inline operands instead of LDS
-enum PowKind { POW_CBRT = 0, POW_GAMMA = 1 };
+enum PowKind { POW_CBRT = 0, POW_GAMMA = 1, POW_DECODE = 2 };
 template <int KIND> struct PowCoef;
 template <> struct PowCoef<POW_CBRT> {
     static constexpr double c1 = 0x1.5555560000000p-2, c2 = -0x1.c71c7238e38e0p-4, c3 = 0x1.f9add40ca4583p-5,
@@ -59,6 +59,17 @@ template <> struct PowCoef<POW_CBRT> {
 template <> struct PowCoef<POW_GAMMA> {
     static constexpr double c1 = 0x1.aaaaaa0000000p-2, c2 = -0x1.f1c71c38e38e0p-4, c3 = 0x1.06b74f00ca456p-4,
                             c4 = -0x1.535770cc3f359p-5, c5 = 0x1.e663bb5d82900p-6;
+};
+
+// c = f32(2.4): srgb_to_linear of the Godot-legacy shader flavour (rust-godot-legacy/.../wgpu_shader.wgsl:89-97)
+template <> struct PowCoef<POW_DECODE> {
+    static constexpr double c1 = 0x1.3333340000000p+1, c2 = 0x1.ae147deb85200p+0, c3 = 0x1.cac08d7b90194p-3,
+                            c4 = -0x1.13405205bbf99p-5, c5 = 0x1.60525321e5f53p-7;
+};
+
+// Tables only the Godot-legacy flavour reads (from global memory; that flavour is not a throughput path)
+struct LegacyTables {
+    PowTable decode;  // c = f32(2.4)
 };
 
 // wgsl:78 `c.z * 2.0 * 3.14159265359`, wgsl:72 `2.0 * 3.14159265359`
@@ -206,6 +217,20 @@ RPF_HD float pow_1p5(float x)
 {
     const double xd = (double)x;
     return (float)(xd * __builtin_sqrt(xd));
+}
+
+// pow(x, 4.0) correctly rounded for finite x >= 0 (Godot-legacy vignette falloff): x^2 is exact in binary64,
+// x^4 = hi + lo with hi = RN(x^2 * x^2) and lo the exact fma residual; hi is then rounded to odd with lo as
+// the sticky information, after which the single rounding to binary32 is the correct one (53 >= 24 + 2).
+RPF_HD float pow_4(float x)
+{
+    const double s = (double)x * (double)x;
+    const double hi = s * s;
+    const double lo = __builtin_fma(s, s, -hi);
+    uint64_t u = d2u(hi);
+    const uint64_t step = lo > 0.0 ? 1ull : ~0ull;  // hi >= 0: towards lo is +1 / -1 on the bit pattern
+    u = (lo != 0.0 && (u & 1ull) == 0ull) ? u + step : u;
+    return (float)u2d(u);
 }
 
 }  // namespace rpf

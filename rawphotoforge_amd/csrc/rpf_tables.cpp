@@ -36,4 +36,9 @@ void build_math_tables(MathTables& T)
     }
 }
 
+void build_legacy_tables(LegacyTables& T)
+{
+    build_pow(T.decode, 2.4f);  // rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl:92
+}
+
 }  // namespace rpf

@@ -308,6 +308,11 @@ class PhotoEditor:
     def reset(self) -> None:
         _check(N.lib().rpf_reset(self._h))
 
+    def set_shader_flavour(self, flavour: int) -> None:
+        """FLAVOUR_ACTIVE (rust/photo-editor shader) or FLAVOUR_GODOT_LEGACY (rust-godot-legacy shader:
+        sRGB-encoded input linearised in the kernel, the older vignette)."""
+        _check(N.lib().rpf_set_shader_flavour(self._h, flavour))
+
     @property
     def num_masks(self) -> int:
         v = C.c_uint32(0)

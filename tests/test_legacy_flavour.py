@@ -1,0 +1,140 @@
+"""The Godot-legacy generation of the edit shader (rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl) behind
+rpf_set_shader_flavour: sRGB-encoded input linearised in the kernel (:89-97, :281-283) and the older vignette
+(:173-186).  CPU: oracle known answers and the flavour switch on a headless editor; GPU: bit-exact parity."""
+import numpy as np
+import pytest
+
+import oracle as O
+from tests import util
+
+
+def test_oracle_legacy_vignette_known_answers():
+    # pixel (0, 0) of a 4x4 frame: coord = (-1, -1) * 2.0 / 2 -> dist = sqrt(2), falloff = 1.
+    # vignette = +100 -> strength -2 -> gain 3: clamped to 2 by the legacy shader, kept (<= 4) by the active one.
+    img = np.zeros((4, 4, 4), np.float32)
+    img[..., :3] = 0.05
+    img[..., 3] = 1
+    p = O.EditParameters(vignette=100)
+    flat = O.EditParameters()
+
+    def scaled(gain):
+        s = img.copy()
+        s[..., :3] *= np.float32(gain)
+        return O.apply(s, [flat])[0, 0]
+
+    assert np.array_equal(O.apply(img, [p], legacy="linear")[0, 0], scaled(2.0))
+    assert np.array_equal(O.apply(img, [p])[0, 0], scaled(3.0))
+    # the centre pixel (2, 2): coord = 0 -> falloff 0 -> gain 1 in both generations
+    assert np.array_equal(O.apply(img, [p], legacy="linear")[2, 2], scaled(1.0))
+    # falloff exponent: pixel (3, 2) of an 8x8 frame: coord = ((3/8 - .5) * 2, 0) = (-.25, 0): dist .25 -> falloff 0;
+    # pixel (0, 4): coord = (-1, 0): dist 1 -> t = 1 exactly -> gain = 1 - s
+    img8 = np.zeros((8, 8, 4), np.float32)
+    img8[..., :3] = 0.05
+    p50 = O.EditParameters(vignette=-25)     # strength +0.5 -> gain 0.5 at dist 1
+    s = img8.copy()
+    s[..., :3] *= np.float32(0.5)
+    assert np.array_equal(O.apply(img8, [p50], legacy="linear")[4, 0], O.apply(s, [flat])[4, 0])
+
+
+def test_oracle_legacy_decode_known_answers():
+    # srgb_to_linear: 0 -> 0, 1 -> 1, below the knee c / 12.92; then the identity edit re-encodes
+    img = np.zeros((1, 4, 4), np.float32)
+    img[0, :, :3] = np.float32([0.0, 1.0, 0.04, 0.5])[:, None]
+    out = O.apply(img, [O.EditParameters()], legacy="encoded")
+    lin = np.float32([0.0, 1.0, np.float32(0.04) / np.float32(12.92), O.lib().orc_cr_powf((0.5 + 0.055) / 1.055, 2.4)])
+    want = O.apply(np.concatenate([np.repeat(lin[:, None], 3, 1), np.ones((4, 1), np.float32)], 1)[None], [O.EditParameters()])
+    assert util.ulp_diff(out, want).max() <= 1   # (c + 0.055) / 1.055 evaluated in f32 vs the literal above
+
+
+def test_flavour_switch_on_headless_editor():
+    import rawphotoforge_amd as R
+    ed = R.PhotoEditor.headless(8, 8)
+    ed.set_shader_flavour(R.FLAVOUR_GODOT_LEGACY)
+    ed.set_shader_flavour(R.FLAVOUR_ACTIVE)
+    with pytest.raises(R.InvalidArgument):
+        ed.set_shader_flavour(2)
+
+
+def _rgb_image(h, w, seed=3):
+    rng = np.random.default_rng(seed)
+    img = rng.random((h, w, 3), dtype=np.float32) * np.float32(1.2) - np.float32(0.05)   # below 0 and above 1 too
+    img[0, :8] = 0
+    img[1, :4] = np.float32(0.04045)
+    return img
+
+
+def _exact(got, want):
+    got = np.asarray(got, np.float32).reshape(want.shape)
+    d = util.ulp_diff(got, want)
+    assert d.max() == 0, f"{int((d > 0).sum())} of {d.size} values differ, max {int(d.max())} ulp"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vignette,lens", [(0, 0), (-60, 0), (100, 0), (35, 40), (-100, -30)])
+def test_gpu_legacy_rgb_editor_bit_exact(gpu, vignette, lens):
+    import rawphotoforge_amd as R
+    h, w = 75, 118
+    img = _rgb_image(h, w)
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    p = util.params_S()
+    p.vignette, p.lens_distortion = vignette, lens
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    util.configure_editor(ed, p)
+    ed.set_shader_flavour(R.FLAVOUR_GODOT_LEGACY)
+    ed.apply_adjustments()
+    _exact(ed.to_flat_vec_rgba(), O.apply(rgba, [p], legacy="encoded"))
+    ed.set_shader_flavour(R.FLAVOUR_ACTIVE)          # and back
+    ed.apply_adjustments()
+    _exact(ed.to_flat_vec_rgba(), O.apply(rgba, [p]))
+
+
+@pytest.mark.gpu
+def test_gpu_legacy_with_masks_and_curves(gpu):
+    import rawphotoforge_amd as R
+    h, w = 40, 72
+    img = _rgb_image(h, w, seed=9)
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    rng = np.random.default_rng(5)
+    pm, p1 = util.params_G(), util.params_S()
+    pm.vignette = -45
+    mask = rng.random((h, w), dtype=np.float32)
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    ed.add_mask("m1", mask)
+    util.configure_editor(ed, pm)
+    util.configure_editor(ed, p1, mask_name="m1", main=False)
+    ed.set_shader_flavour(R.FLAVOUR_GODOT_LEGACY)
+    ed.apply_adjustments()
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(mask, pm.mask_range)])
+    _exact(ed.to_flat_vec_rgba(), O.apply(rgba, [pm, p1], masks=masks, legacy="encoded"))
+
+
+@pytest.mark.gpu
+def test_gpu_legacy_bayer_editor_and_device_layer(gpu):
+    torch = pytest.importorskip("torch")
+    import rawphotoforge_amd as R
+    h, w = 66, 100
+    cfa = util.bayer_natural(h, w)
+    rp = util.raw_params()
+    p = util.params_S()
+    p.vignette = 70
+    ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+    util.configure_editor(ed, p)
+    ed.set_shader_flavour(R.FLAVOUR_GODOT_LEGACY)
+    ed.apply_adjustments()
+    lin = O.demosaic(cfa, rp)                       # the frame is linear already: only the vignette changes
+    want = O.apply(lin, [p], legacy="linear")
+    _exact(ed.to_flat_vec_rgba(), want)
+    # device-pointer layer: the fused kernel is the active shader only; demosaic + apply serves the legacy one
+    t = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+    util.configure_editor(t, p)
+    t.set_shader_flavour(R.FLAVOUR_GODOT_LEGACY)
+    band = torch.zeros((h + 4, w), dtype=torch.int16, device="cuda")
+    band[2:h + 2] = torch.from_numpy(cfa.view(np.int16)).cuda()
+    out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(R.InvalidArgument):
+        t.dev_develop(band.data_ptr(), util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32, s)
+    enc = torch.from_numpy(np.ascontiguousarray(lin)).cuda()
+    t.dev_apply(enc.data_ptr(), out.data_ptr(), R.OUT_RGBA_F32, s)     # tile input is taken as sRGB-encoded
+    torch.cuda.synchronize()
+    _exact(out.cpu().numpy(), O.apply(lin, [p], legacy="encoded"))

@@ -103,3 +103,34 @@ def test_division_by_two_pi_every_atan2_result():
         tw.twin_div_two_pi.restype = C.c_float
         tw.twin_div_two_pi.argtypes = [C.c_float]
         assert np.float32(tw.twin_div_two_pi(x)) == np.float32(x) / d
+
+
+# ---- Godot-legacy shader flavour (rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl:89-97, 173-186) ----
+
+def test_pow_2p4_every_float_in_the_srgb_decode_domain():
+    # srgb_to_linear takes the pow branch above 0.04045: (c + 0.055) / 1.055 > 0.0904 > 2^-4; up to 2.0 for HDR input
+    n, bad = _sweep(2, float(np.float32(2.4)), 2.0 ** -4, 2.0)
+    assert n > 40_000_000 and bad == []
+
+
+def test_pow_4_is_exact():
+    # error-free by construction; every float of the top four binades of [0, 1], samples of the rest
+    n, bad = _sweep(3, 4.0, 2.0 ** -4, 1.0 + 2.0 ** -20)
+    assert n > 33_000_000 and bad == []
+    tw, orc = util.twin(), O.lib()
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([(rng.random(50_000) * 10.0 ** rng.uniform(-9, 0, 50_000)).astype(np.float32),
+                         np.float32([0.0, 1.0, 1e-12, 1e-30, 0.5, 0.70710677])])
+    for x in xs.tolist():
+        assert tw.twin_pow_4(x) == orc.orc_cr_powf(x, 4.0), x
+
+
+def test_srgb_to_linear_matches_oracle_on_every_16_bit_and_8_bit_code():
+    tw, orc = util.twin(), O.lib()
+    orc.orc_srgb_to_linear1.restype = C.c_float
+    orc.orc_srgb_to_linear1.argtypes = [C.c_float]
+    codes = np.concatenate([np.arange(65536, dtype=np.float32) / np.float32(65535.0),
+                            np.arange(256, dtype=np.float32) / np.float32(255.0),
+                            np.float32([0.04045, np.nextafter(np.float32(0.04045), np.float32(1)), 1.5, 0.0])])
+    for c in codes.tolist():
+        assert tw.twin_srgb_to_linear(c) == orc.orc_srgb_to_linear1(c), c

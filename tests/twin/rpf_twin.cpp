@@ -7,7 +7,10 @@
 #include <stdint.h>
 #include <string.h>
 
-namespace rpf { void build_math_tables(MathTables& T); }
+namespace rpf {
+void build_math_tables(MathTables& T);
+void build_legacy_tables(LegacyTables& T);
+}
 
 static rpf::MathTables g_tab;
 static bool g_ready = false;
@@ -15,6 +18,14 @@ static const rpf::MathTables& tabs()
 {
     if (!g_ready) { rpf::build_math_tables(g_tab); g_ready = true; }
     return g_tab;
+}
+
+static const rpf::LegacyTables& legacy_tabs()
+{
+    static rpf::LegacyTables t;
+    static bool ready = false;
+    if (!ready) { rpf::build_legacy_tables(t); ready = true; }
+    return t;
 }
 
 struct HostLuts {
@@ -40,6 +51,12 @@ float twin_pow_gamma(float x) { return rpf::powc<rpf::POW_GAMMA>(x, tabs().gamma
 float twin_atan2(float y, float x) { return rpf::atan2_cr(y, x); }
 void twin_sincos_hue(uint32_t k, float* cs, float* sn) { rpf::sincos_hue(k, tabs().sc, *cs, *sn); }
 float twin_pow_1p5(float x) { return rpf::pow_1p5(x); }
+float twin_pow_4(float x) { return rpf::pow_4(x); }
+float twin_srgb_to_linear(float c) { return rpf::srgb_to_linear1(c, legacy_tabs().decode); }
+float twin_vignette_gain(int legacy, float strength, int x, int y, float w, float h)
+{
+    return legacy ? rpf::vignette_gain_legacy(strength, x, y, w, h) : rpf::vignette_gain(strength, x, y, w, h);
+}
 float twin_div_u16(uint32_t k, float d) { return rpf::div_u16_by(k, d, 1.0f / d); }
 float twin_div_two_pi(float x) { return rpf::div_by_const(x, RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F)); }
 void twin_div_two_pi_range(uint32_t bits_lo, uint32_t n, float* out)
@@ -58,10 +75,14 @@ float twin_hue_angle(uint32_t k)
 void twin_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
 {
     const rpf::MathTables& T = tabs();
+    const rpf::LegacyTables& L = legacy_tabs();
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < (long long)n; ++i) {
         float x = rpf::bits2f(bits_lo + (uint32_t)i);
-        out[i] = which == 0 ? rpf::powc<rpf::POW_CBRT>(x, T.cbrt) : rpf::powc<rpf::POW_GAMMA>(x, T.gamma);
+        out[i] = which == 0   ? rpf::powc<rpf::POW_CBRT>(x, T.cbrt)
+                 : which == 1 ? rpf::powc<rpf::POW_GAMMA>(x, T.gamma)
+                 : which == 2 ? rpf::powc<rpf::POW_DECODE>(x, L.decode)
+                              : rpf::pow_4(x);
     }
 }
 

@@ -34,6 +34,11 @@ def twin():
     global _twin
     if _twin is None:
         _twin = C.CDLL(build_twin())
+        for n in ("twin_pow_4", "twin_srgb_to_linear"):
+            getattr(_twin, n).restype = C.c_float
+            getattr(_twin, n).argtypes = [C.c_float]
+        _twin.twin_vignette_gain.restype = C.c_float
+        _twin.twin_vignette_gain.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float]
         for n in ("twin_pow_cbrt", "twin_pow_gamma", "twin_pow_1p5", "twin_hue_angle"):
             getattr(_twin, n).restype = C.c_float
         _twin.twin_pow_cbrt.argtypes = [C.c_float]
