@@ -16,6 +16,7 @@
 namespace rpf {
 void build_math_tables(MathTables& T);
 void build_legacy_tables(LegacyTables& T);
+void build_hue_bounds(HueBound* B);
 }
 
 using namespace rpf;
@@ -73,6 +74,7 @@ struct rpf_processor {
     int variant = 0;
     MathTables* d_tabs = nullptr;
     LegacyTables* d_legacy = nullptr;  // Godot-legacy flavour only
+    HueBound* d_hue_bounds = nullptr;  // 65536 entries, 1 MiB
     std::atomic<int> editors{0};
 };
 
@@ -152,6 +154,7 @@ static int sync_edit_state_impl(rpf_editor* e)
         e->dev.hsl = e->d_hsl;
         e->dev.tabs = e->proc->d_tabs;
         e->dev.legacy = e->proc->d_legacy;
+        e->dev.hue_bounds = e->proc->d_hue_bounds;
         e->uploaded_params = e->state.params_version;
     }
     if (e->uploaded_masks != e->state.masks_version) {
@@ -260,12 +263,18 @@ int rpf_processor_create(int device, rpf_processor** out)
     if (e != hipSuccess) { (void)hipFree(p->d_tabs); return hip_fail(e, "hipMemcpy(tables)", RPF_ERR_GPU_INITIALIZATION); }
     std::unique_ptr<LegacyTables> legacy(new LegacyTables);
     build_legacy_tables(*legacy);
+    std::vector<HueBound> bounds(RPF_CURVE_RESOLUTION);
+    build_hue_bounds(bounds.data());
     e = hipMalloc((void**)&p->d_legacy, sizeof(LegacyTables));
     if (e == hipSuccess) e = hipMemcpy(p->d_legacy, legacy.get(), sizeof(LegacyTables), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_hue_bounds, bounds.size() * sizeof(HueBound));
+    if (e == hipSuccess)
+        e = hipMemcpy(p->d_hue_bounds, bounds.data(), bounds.size() * sizeof(HueBound), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(p->d_tabs);
         if (p->d_legacy) (void)hipFree(p->d_legacy);
-        return hip_fail(e, "legacy tables", RPF_ERR_GPU_INITIALIZATION);
+        if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
+        return hip_fail(e, "tables", RPF_ERR_GPU_INITIALIZATION);
     }
     *out = p.release();
     return ok();
@@ -277,6 +286,7 @@ void rpf_processor_destroy(rpf_processor* p)
     if (hipSetDevice(p->device) == hipSuccess) {
         if (p->d_tabs) (void)hipFree(p->d_tabs);
         if (p->d_legacy) (void)hipFree(p->d_legacy);
+        if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
     }
     delete p;
 }

@@ -255,8 +255,9 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         mask_rgb_stage<N>(mp[m], m, luts, r, g, b, act);
     }
 
-    // linear_srgb_to_oklch, wgsl:64-75
+    // linear_srgb_to_oklch, wgsl:64-75.  The hue is only ever used as a curve index (hue_index, rpf_math.h).
     float L[N], C[N], h[N];
+    uint32_t hu0[N];
     for (int n = 0; n < N; ++n) {
         const float l = RPF_F(0.4122214708) * r[n] + RPF_F(0.5363325363) * g[n] + RPF_F(0.0514459929) * b[n];
         const float mm = RPF_F(0.2119034982) * r[n] + RPF_F(0.6806995451) * g[n] + RPF_F(0.1073969566) * b[n];
@@ -268,28 +269,29 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
         const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;
         C[n] = __builtin_sqrtf(A * A + Bq * Bq);
-        float hh = div_by_const(atan2_cr(Bq, A), RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F));
-        h[n] = hh < 0.0f ? hh + 1.0f : hh;
+        hu0[n] = hue_index(Bq, A, luts.hue_bounds());  // u32(h * 65535), h = atan2(b, a) / (2 pi) wrapped, wgsl:72-73, 320
     }
 
     // per-mask OKLCH curves, wgsl:312-331
     uint32_t hue_k[N];
-    for (uint32_t m = 0; m < num_masks; ++m) {
+    auto oklch_stage = [&](uint32_t m, bool main_mask) {
         const MaskParams& P = mp[m];
         const bool trivial = (P.flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
                              (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
         for (int n = 0; n < N; ++n) {
-            const uint32_t hu = (uint32_t)(h[n] * 65535.0f);
+            const uint32_t hu = main_mask ? hu0[n] : (uint32_t)(h[n] * 65535.0f);
             uint32_t nh = hu;
             float sat_gain = P.sat_gain, light_gain = P.light_gain;
             if (!trivial) luts.hsl(m, hu, P, nh, sat_gain, light_gain);
-            const bool on = m == 0 ? true : (bool)((active[n] >> m) & 1u);
+            const bool on = main_mask ? true : (bool)((active[n] >> m) & 1u);
             hue_k[n] = on ? nh : hue_k[n];
             h[n] = on ? div_u16_by(nh, 65535.0f, inv65535) : h[n];
             C[n] = on ? C[n] * sat_gain : C[n];
             L[n] = on ? L[n] * light_gain : L[n];
         }
-    }
+    };
+    oklch_stage(0u, true);  // "main" is always active and replaces the hue by curve[k] / 65535
+    for (uint32_t m = 1; m < num_masks; ++m) oklch_stage(m, false);
 
     // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336).  The hue reaching
     // here is always k/65535 for the integer k the last active mask fetched ("main" is always active).

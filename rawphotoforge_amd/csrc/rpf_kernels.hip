@@ -28,7 +28,9 @@
 
 namespace rpf {
 
-enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2 };  // _SEQ (A/B only): the pair one pixel after the other
+// _SEQ (A/B only): the pair one pixel after the other.  _1: only the "main" mask exists (the common case): the
+// per-mask loops and the mask-plane reads are compiled out, which also frees the scalar registers they pin.
+enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2, MODE_DEVELOP_1 = 3 };
 enum { OUT_RGBA_F32_PLAIN = 3 };  // internal (A/B only): RGBA32F with ordinary stores
 
 // ---------------------------------------------------------------------------
@@ -39,6 +41,8 @@ struct DevLuts {
     const uint16_t* lds_bright;  // mask 0's brightness curve in LDS (LDS_LUT)
     const uint16_t* g_bright;
     const ushort4* g_hsl;
+    const HueBound* g_hue_bounds;
+    __device__ __forceinline__ const HueBound* hue_bounds() const { return g_hue_bounds; }
     __device__ __forceinline__ uint32_t brightness(uint32_t m, uint32_t i) const
     {
         if (LDS_LUT && m == 0) return lds_bright[i];
@@ -156,9 +160,11 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
             }
         }
         uint32_t active[2] = {1u, 1u};
-        if (ed.num_masks > 1)
+        if (MODE != MODE_DEVELOP_1 && ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(ed, pix[k], (size_t)rows * W);
-        if (MODE == MODE_DEVELOP_SEQ) {
+        if (MODE == MODE_DEVELOP_1) {
+            edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
+        } else if (MODE == MODE_DEVELOP_SEQ) {
             for (int k = 0; k < 2; ++k) {
                 float r1[1] = {r[k]}, g1[1] = {gg[k]}, b1[1] = {b[k]};
                 const uint32_t a1[1] = {active[k]};
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds};
 
     const int lane = tid & 63;
     const int W = (int)a.g.width, H = (int)a.g.height;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
     const int lx = tid & (TILE_W - 1);
     const int ly = 2 * (tid / TILE_W);
     const int lane = tid & 63;
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds};
 
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         const int tx0 = (int)(t % a.tiles_x) * TILE_W;
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     const int tid = threadIdx.x;
     stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     __syncthreads();
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds};
     const int W = (int)a.g.width, H = (int)a.g.height;
     const size_t npix = (size_t)a.g.rows * W;
     const size_t stride = (size_t)gridDim.x * NT * 2;
@@ -596,7 +602,7 @@ static hipError_t check_geom(const TileGeom& g, bool bayer)
 
 static hipError_t check_edit(const DeviceEdit& ed)
 {
-    if (!ed.tabs || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS) return hipErrorInvalidValue;
+    if (!ed.tabs || !ed.hue_bounds || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS) return hipErrorInvalidValue;
     if (ed.num_masks > 1 && !ed.mask_planes) return hipErrorInvalidValue;
     return hipSuccess;
 }
@@ -622,8 +628,12 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     constexpr uint32_t WPB = NT / 64;
     uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
     if (MODE != MODE_DEMOSAIC) {
-        // persistent workgroups (LDS tables staged once per workgroup), as many as are resident
-        const uint32_t cap = (uint32_t)cfg.num_cus * (LDS_LUT ? 1u : (uint32_t)(1024 / NT));
+        // persistent workgroups (LDS tables staged once per workgroup), as many as are resident: the fused kernel
+        // needs < 96 VGPRs, i.e. 5 waves per SIMD (variant 6: 4, for A/B); the 128-KiB curve in LDS limits that
+        // variant to one 1024-thread workgroup per CU.  (Cutting the last, incomplete round of items into
+        // single-pair sub-items was tried: no measurable change, profiles/r01_experiments.md.)
+        uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
+        const uint32_t cap = (uint32_t)cfg.num_cus * per_cu;
         if (grid > cap) grid = cap;
     } else if (blocks_per_cu) {
         const uint32_t cap = (uint32_t)cfg.num_cus * blocks_per_cu;
@@ -682,6 +692,9 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
                    : run_stream<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     if (OUTFMT == OUT_RGBA_F32 && !lut && cfg.variant == 3)  // A/B: the pixel pair one after the other
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    if (ed.num_masks == 1 && cfg.variant != 7)  // variant 7 (A/B): the general kernel on a single mask
+        return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
+                   : run_stream<256, MODE_DEVELOP_1, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
 }

@@ -211,6 +211,60 @@ RPF_HD void sincos_hue(uint32_t k, const TabT& S, float& cs, float& sn)
     sn = (float)__builtin_fma(ce, delta, se * q);
 }
 
+// ---------------------------------------------------------------------------
+// Hue index without an arctangent.
+//
+// The chain needs atan2 for one thing only: k = u32(h * 65535) with h = atan2(b, a) / (2 pi) wrapped into
+// [0, 1) (wgsl:72-73, 320), the index of the per-hue curves; the hue itself is then replaced by curve[k] / 65535.
+// k is a circularly monotone step function of the true angle, so it is fixed by 65536 boundary directions:
+// HueBound[j] = (cos, sin) of the angle at which k first reaches j, i.e. the midpoint between the two adjacent
+// binary32 values t' < t of the correctly rounded atan2 with k(t') < j <= k(t)  (built by build_hue_bounds from
+// the same binary32 pipeline: t / f32(2 pi), +1 if negative, * 65535, truncate).  A cheap approximation of the
+// angle (error < 0.2 index units) picks the one boundary that can matter, and the sign of the binary64 cross
+// product  b cos - a sin  decides on which side of it (a, b) lies — the same decision the correctly rounded
+// atan2 followed by the binary32 pipeline makes.  1 MiB table, read from L2.
+// One corner is left out: for a true angle in (-3.5 * 2^-149, 0) the reference's t / f32(2 pi) underflows to -0
+// and k = 0, here k = 65535.  That needs b < 0 with |b| < 4.9e-45 |a|; in the chain a nonzero |b| is at least
+// ~2^-75 (a rounded sum of three products of cube roots >= 2^-50) and |a| < 8, so it cannot occur.
+// ---------------------------------------------------------------------------
+struct HueBound {
+    double c, s;
+};
+
+RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = ax > ay ? ax : ay;
+    const float mn = ax > ay ? ay : ax;
+    // scale so that mx lands in [1, 2): the reciprocal below neither overflows nor meets a denormal
+    uint32_t eb = f2bits(mx) >> 23;
+    eb = eb > 253u ? 253u : eb;
+    const float sc = bits2f((254u - eb) << 23);
+    const float mxs = mx * sc, mns = mn * sc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float q = mns * __builtin_amdgcn_rcpf(mxs);
+#else
+    const float q = mxs > 0.0f ? mns / mxs : 0.0f;
+#endif
+    // atan(q) * 65535 / (2 pi) for q in [0, 1], |error| < 0.12 index units (tools/gen_math_consts.py)
+    const float z = q * q;
+    float p = __builtin_fmaf(z, 217.41815f, -888.19727f);
+    p = __builtin_fmaf(z, p, 1879.0994f);
+    p = __builtin_fmaf(z, p, -3445.1509f);
+    p = __builtin_fmaf(z, p, 10428.825f);
+    float v = p * q;
+    v = ay > ax ? 16383.75f - v : v;   // pi/2 - a
+    v = x < 0.0f ? 32767.5f - v : v;   // pi - a
+    v = y < 0.0f ? 65535.0f - v : v;   // 2 pi - a (the wrap of wgsl:73); y = -0 counts as +0, like atan2's -0 result
+    const uint32_t j = (uint32_t)(v + 0.5f) & 0xffffu;
+    const HueBound bd = hb[j];
+    const double d = __builtin_fma((double)y, bd.c, -((double)x * bd.s));
+    uint32_t k = (j - (d >= 0.0 ? 0u : 1u)) & 0xffffu;
+    // atan2(+-0, +0) = +-0 -> 0;  atan2(+-0, -0) = +-pi -> 32767
+    k = mx == 0.0f ? ((f2bits(x) >> 31) ? 32767u : 0u) : k;
+    return k;
+}
+
 // pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171):
 // x*sqrt(x) in binary64 is within 2^-52 of the true value.
 RPF_HD float pow_1p5(float x)

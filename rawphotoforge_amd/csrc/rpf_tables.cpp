@@ -36,6 +36,44 @@ void build_math_tables(MathTables& T)
     }
 }
 
+// wgsl:72-73 and :320 on a correctly rounded atan2 result t
+static uint32_t hue_pipeline(float t)
+{
+    const float hh = t / RPF_K_TWO_PI_F;
+    const float h = hh < 0.0f ? hh + 1.0f : hh;
+    return (uint32_t)(h * 65535.0f);
+}
+
+void build_hue_bounds(HueBound* B)
+{
+    const uint32_t pi_bits = f2bits(RPF_K_PI_F);  // RN(pi): the largest magnitude atan2 returns
+    const uint32_t k_pi = hue_pipeline(RPF_K_PI_F);
+    B[0].c = 1.0;
+    B[0].s = 0.0;
+    for (uint32_t j = 1; j < 65536; ++j) {
+        long double theta;
+        if (j <= k_pi) {  // first reached on the upper half circle: smallest t in [0, pi] with k(t) >= j
+            uint32_t lo = 0, hi = pi_bits;  // k(lo) < j <= k(hi)
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (hue_pipeline(bits2f(mid)) >= j) hi = mid; else lo = mid;
+            }
+            theta = ((long double)bits2f(lo) + (long double)bits2f(hi)) / 2.0L;
+        } else {  // lower half circle, t = -m running from -pi up to -0: largest m with k(-m) >= j
+            // k(-m) = 65535 down to m = 4 * 2^-149; below that t / f32(2 pi) underflows to -0 and k = 0 — angles
+            // in (-3.5 * 2^-149, 0) are left to boundary 0 = angle 0 (see hue_index: not reachable by the chain)
+            uint32_t lo = 4, hi = pi_bits;  // k(-lo) >= j > k(-hi)   (k(-pi) = k_pi)
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (hue_pipeline(-bits2f(mid)) >= j) lo = mid; else hi = mid;
+            }
+            theta = -((long double)bits2f(lo) + (long double)bits2f(hi)) / 2.0L;
+        }
+        B[j].c = (double)cosl(theta);
+        B[j].s = (double)sinl(theta);
+    }
+}
+
 void build_legacy_tables(LegacyTables& T)
 {
     build_pow(T.decode, 2.4f);  // rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl:92

@@ -134,3 +134,67 @@ def test_srgb_to_linear_matches_oracle_on_every_16_bit_and_8_bit_code():
                             np.float32([0.04045, np.nextafter(np.float32(0.04045), np.float32(1)), 1.5, 0.0])])
     for c in codes.tolist():
         assert tw.twin_srgb_to_linear(c) == orc.orc_srgb_to_linear1(c), c
+
+
+# ---- hue index without an arctangent (rpf_math.h hue_index) ----
+
+def _hue_both(y, x):
+    tw, orc = util.twin(), O.lib()
+    y = np.ascontiguousarray(y, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    a, b = np.empty(y.size, np.uint32), np.empty(y.size, np.uint32)
+    tw.twin_hue_index_many(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_size_t(y.size),
+                           a.ctypes.data_as(C.c_void_p))
+    orc.orc_hue_index_many(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_size_t(y.size),
+                           b.ctypes.data_as(C.c_void_p))
+    return a, b
+
+
+def test_hue_index_random_directions_and_magnitudes():
+    rng = np.random.default_rng(21)
+    n = 6_000_000
+    y = (rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 2, n)).astype(np.float32)
+    x = (rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 2, n)).astype(np.float32)
+    a, b = _hue_both(y, x)
+    assert np.array_equal(a, b), np.nonzero(a != b)[0][:10]
+    # what the chain produces: |a|, |b| <= ~0.5 with both near zero for greys
+    th = rng.uniform(-np.pi, np.pi, n)
+    r = 10.0 ** rng.uniform(-8, -0.3, n)
+    a, b = _hue_both(r * np.sin(th), r * np.cos(th))
+    assert np.array_equal(a, b)
+
+
+def test_hue_index_next_to_every_boundary():
+    # directions a few binary32 steps of the angle either side of each of the 65536 boundaries, at several radii
+    tw = util.twin()
+    cs = np.empty((65536, 2))
+    c, s = C.c_double(), C.c_double()
+    for j in range(65536):
+        tw.twin_hue_bound(C.c_uint32(j), C.byref(c), C.byref(s))
+        cs[j] = (c.value, s.value)
+    theta = np.arctan2(cs[:, 1], cs[:, 0])
+    assert abs(theta[1] - 2 * np.pi / 65535) < 1e-6 and abs(theta[65534] + 2 * np.pi / 65535) < 1e-6
+    assert np.all(np.diff(np.where(theta < 0, theta + 2 * np.pi, theta)[:65535]) > 0)   # counter-clockwise order
+    rng = np.random.default_rng(22)
+    for radius in (1.0, 0.37, 3e-3, 2.5e-7):
+        for steps in (-40, -3, -1, -0.5, -0.1, 0.1, 0.5, 1, 3, 40):
+            # (boundary 0 is the angle 0 itself: step in units of 1e-30 there, clear of the documented -1e-45 corner)
+            ulp = np.spacing(np.maximum(np.abs(theta), 1e-30).astype(np.float32)).astype(np.float64)
+            t = theta + steps * ulp
+            rr = radius * rng.uniform(0.5, 1.0, t.size)
+            a, b = _hue_both(rr * np.sin(t), rr * np.cos(t))
+            assert np.array_equal(a, b), (radius, steps, np.nonzero(a != b)[0][:10])
+
+
+def test_hue_index_special_arguments():
+    z, nz = 0.0, -0.0
+    cases = [(z, z), (nz, z), (z, nz), (nz, nz), (z, 1), (nz, 1), (z, -1), (nz, -1), (1, z), (1, nz), (-1, z), (-1, nz),
+             (1e-30, 1), (-1e-30, 1), (1e-30, -1), (-1e-30, -1), (1, 1e-30), (1, -1e-30), (1, 1), (-1, 1), (1, -1), (-1, -1),
+             (3e-39, 1e-39), (-3e-39, 1e-39), (1e-39, -3e-39), (1e38, 1e38), (-1e38, 3e38), (1e-45, 1e-45), (-1e-45, -1e-45),
+             (-1e-7, 1), (-1.9e-7, 1), (-2e-7, 1), (6e-8, -1), (-6e-8, -1)]
+    y, x = np.float32([c[0] for c in cases]), np.float32([c[1] for c in cases])
+    a, b = _hue_both(y, x)
+    assert np.array_equal(a, b), [(cases[i], int(a[i]), int(b[i])) for i in np.nonzero(a != b)[0]]
+    # the documented exception: a true angle in (-3.5 * 2^-149, 0) — unreachable from the chain
+    a, b = _hue_both(np.float32([-1e-45]), np.float32([1.0]))
+    assert (int(a[0]), int(b[0])) == (65535, 0)

@@ -10,6 +10,7 @@
 namespace rpf {
 void build_math_tables(MathTables& T);
 void build_legacy_tables(LegacyTables& T);
+void build_hue_bounds(HueBound* B);
 }
 
 static rpf::MathTables g_tab;
@@ -28,6 +29,13 @@ static const rpf::LegacyTables& legacy_tabs()
     return t;
 }
 
+static const rpf::HueBound* hue_bounds_tab()
+{
+    static rpf::HueBound* t = nullptr;
+    if (!t) { t = new rpf::HueBound[65536]; rpf::build_hue_bounds(t); }
+    return t;
+}
+
 struct HostLuts {
     const int32_t* bright; const int32_t* hue; const int32_t* sat; const int32_t* light;
     static uint32_t fetch(const int32_t* l, uint32_t m, uint32_t i)
@@ -35,6 +43,7 @@ struct HostLuts {
         int32_t v = l[(size_t)m * RPF_CURVE_RESOLUTION + i];
         return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
     }
+    const rpf::HueBound* hue_bounds() const { return hue_bounds_tab(); }
     uint32_t brightness(uint32_t m, uint32_t i) const { return fetch(bright, m, i); }
     void hsl(uint32_t m, uint32_t i, const rpf::MaskParams&, uint32_t& nh, float& sg, float& lg) const
     {
@@ -52,6 +61,21 @@ float twin_atan2(float y, float x) { return rpf::atan2_cr(y, x); }
 void twin_sincos_hue(uint32_t k, float* cs, float* sn) { rpf::sincos_hue(k, tabs().sc, *cs, *sn); }
 float twin_pow_1p5(float x) { return rpf::pow_1p5(x); }
 float twin_pow_4(float x) { return rpf::pow_4(x); }
+uint32_t twin_hue_index(float y, float x) { return rpf::hue_index(y, x, hue_bounds_tab()); }
+// the path hue_index replaces: correctly rounded atan2 (here the binary64 twin) through the binary32 pipeline
+uint32_t twin_hue_index_via_atan2(float y, float x)
+{
+    const float hh = rpf::div_by_const(rpf::atan2_cr(y, x), RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F));
+    const float h = hh < 0.0f ? hh + 1.0f : hh;
+    return (uint32_t)(h * 65535.0f);
+}
+void twin_hue_index_many(const float* y, const float* x, size_t n, uint32_t* out)
+{
+    const rpf::HueBound* hb = hue_bounds_tab();
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) out[i] = rpf::hue_index(y[i], x[i], hb);
+}
+void twin_hue_bound(uint32_t j, double* c, double* s) { *c = hue_bounds_tab()[j].c; *s = hue_bounds_tab()[j].s; }
 float twin_srgb_to_linear(float c) { return rpf::srgb_to_linear1(c, legacy_tabs().decode); }
 float twin_vignette_gain(int legacy, float strength, int x, int y, float w, float h)
 {
