@@ -32,8 +32,12 @@ BYTES_PER_PX = {"develop": 18, "demosaic": 18, "apply": 32,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--preheat", type=int, default=200,
+                    help="untimed steps before the W warmup steps (same count on every rank): an idle MI355X needs "
+                         "~50 launches (15 ms) to reach its steady clocks, and steady state is what a production "
+                         "service sees (profiles/r01_experiments.md)")
     ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply", "unpack"])
     ap.add_argument("--params", default="D", choices=["D", "S", "G"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
@@ -108,6 +112,10 @@ def main():
         if i is not None:
             ev[i][1].record()
 
+    preheat_steps = max(0, args.preheat)
+    for _ in range(preheat_steps):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -146,7 +154,7 @@ def main():
                          f"data ({args.data}), frame {W}x{frame_h} in {world} row band(s)"
                          + (", 2-row halo exchange per step" + ("" if args.no_overlap else
                             " hidden behind the interior rows (edge rows launched after it)") if world > 1 else "")),
-            "variant": args.variant, "out": args.out, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
+            "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
             "kernel_ms_min": round(kern_ms[0], 4),
         },
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -358,7 +358,7 @@ class PhotoEditor:
     # -- device-pointer layer (rpf_dev_*) -------------------------------------------------------
     def dev_develop(self, d_cfa_ptr: int, raw: RawParams, d_out_ptr: int, out_format: int = N.OUT_RGBA_F32,
                     stream: int = 0) -> None:
-        rp = raw.to_c()
+        rp = raw if isinstance(raw, N.RawParams) else raw.to_c()  # a prebuilt rpf_raw_params skips the conversion
         _check(N.lib().rpf_dev_develop(self._h, C.c_void_p(d_cfa_ptr), C.byref(rp), C.c_void_p(d_out_ptr),
                                        out_format, C.c_void_p(stream)))
 

@@ -26,22 +26,16 @@ def split_rows(height: int, world: int) -> List[Tuple[int, int]]:
     return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
 
 
-def exchange_halos(band, rank: int, world: int, group=None) -> None:
-    """Fill `band`'s halo rows from the neighbouring ranks' edge rows.
-
-    band: torch tensor (rows + 4, W), any 2-byte dtype, contiguous, on the rank's device (or CPU for
-    gloo).  One batch of point-to-point ops; returns when the halos are usable on the current stream.
-    """
-    import torch.distributed as dist
-
-    if world == 1:
-        return
+def halo_ops(band, rank: int, world: int, group=None) -> list:
+    """The point-to-point operations of one halo exchange of `band` (views of it, no copies).  The list can be
+    kept and handed to `torch.distributed.batch_isend_irecv` every step while `band` stays the same tensor."""
     import torch
+    import torch.distributed as dist
 
     rows = band.shape[0] - 2 * HALO
     if rows < HALO:
         raise ValueError("a band must have at least 2 rows to feed its neighbours' halos")
-    # RCCL/NCCL has no 16-bit integer datatype: ship the rows as bytes (views, no copies)
+    # RCCL/NCCL has no 16-bit integer datatype: ship the rows as bytes
     raw = band.view(torch.uint8) if band.dtype != torch.uint8 else band
     ops = []
     if rank > 0:  # neighbour above: my first two rows are its bottom halo
@@ -50,7 +44,21 @@ def exchange_halos(band, rank: int, world: int, group=None) -> None:
     if rank < world - 1:  # neighbour below
         ops.append(dist.P2POp(dist.isend, raw[rows:rows + HALO], rank + 1, group))
         ops.append(dist.P2POp(dist.irecv, raw[rows + HALO:rows + 2 * HALO], rank + 1, group))
-    for req in dist.batch_isend_irecv(ops):
+    return ops
+
+
+def exchange_halos(band, rank: int, world: int, group=None, ops=None) -> None:
+    """Fill `band`'s halo rows from the neighbouring ranks' edge rows.
+
+    band: torch tensor (rows + 4, W), any 2-byte dtype, contiguous, on the rank's device (or CPU for
+    gloo).  One batch of point-to-point ops; returns when the halos are usable on the current stream.
+    `ops`: the list `halo_ops` built for this band earlier (saves rebuilding it every step).
+    """
+    if world == 1:
+        return
+    import torch.distributed as dist
+
+    for req in dist.batch_isend_irecv(ops if ops is not None else halo_ops(band, rank, world, group)):
         req.wait()
 
 
@@ -80,14 +88,19 @@ class BandDeveloper:
 
     EDGE = 8  # rows per edge tile = one work item of the kernel (64 columns x 8 rows)
 
-    def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, rank=0, world=1, overlap=True):
+    def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, rank=0, world=1, overlap=True,
+                 force_split=False):
         import torch
 
         from .editor import PhotoEditor
 
-        self.raw, self.rank, self.world = raw, rank, world
+        self.raw = raw.to_c() if hasattr(raw, "to_c") else raw  # converted once, not per launch
+        self.rank, self.world = rank, world
+        self._ops_for = None  # (band tensor id, data_ptr) the cached P2P op list belongs to
+        self._ops = None
         self.w, self.rows = frame_width, rows
-        self.split = overlap and world > 1 and rows >= 4 * self.EDGE
+        # force_split: the three-launch schedule without neighbours (measuring its host-side cost on one GPU)
+        self.split = ((overlap and world > 1) or force_split) and rows >= 4 * self.EDGE
         self._torch = torch
         e = self.EDGE
         parts = [(0, rows)] if not self.split else [(e, rows - 2 * e), (0, e), (rows - e, e)]
@@ -110,9 +123,15 @@ class BandDeveloper:
             off, _, ed = part
             ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, stream.cuda_stream)
 
+        def exchange_now():
+            key = (id(band), bptr)
+            if self._ops_for != key:
+                self._ops, self._ops_for = halo_ops(band, self.rank, self.world), key
+            exchange_halos(band, self.rank, self.world, ops=self._ops)
+
         if not self.split:
-            if exchange:
-                exchange_halos(band, self.rank, self.world)
+            if exchange and self.world > 1:
+                exchange_now()
             if events:
                 events[0].record(cur)
             launch(self.parts[0], cur)
@@ -126,8 +145,8 @@ class BandDeveloper:
             launch(self.parts[0], self.side)
             if events:
                 events[1].record(self.side)
-        if exchange:
-            exchange_halos(band, self.rank, self.world)
+        if exchange and self.world > 1:
+            exchange_now()
         launch(self.parts[1], cur)
         launch(self.parts[2], cur)
         cur.wait_stream(self.side)

@@ -43,6 +43,19 @@ def _worker(rank, world, rdzv, out_dir):
         p = util.params_S()
         mine = O.develop(virt, util.raw_params(), [p], y0=y0, rows=rows)
         np.save(os.path.join(out_dir, f"band{rank}.npy"), mine)
+        # a second frame through the SAME band buffer with the op list built once (what BandDeveloper does per step)
+        ops = tiles.halo_ops(band, rank, world)
+        for seed in (7, 8):
+            cfa2 = util.bayer_uniform(H, W, seed=seed)
+            band[2:-2] = torch.from_numpy(cfa2[y0:y0 + rows].view(np.int16))
+            dist.barrier()   # every rank has written its rows before anyone's halo is filled
+            tiles.exchange_halos(band, rank, world, ops=ops)
+            got2 = band.numpy().view(np.uint16)
+            if rank > 0:
+                assert np.array_equal(got2[:2], cfa2[y0 - 2:y0])
+            if rank < world - 1:
+                assert np.array_equal(got2[-2:], cfa2[y0 + rows:y0 + rows + 2])
+            dist.barrier()
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ echo "pytest rc=$rc" >> $OUT/gpu_tests.log; tail -4 $OUT/gpu_tests.log; stop_if_
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; rc=$?; tail -1 $OUT/smoke.log; stop_if_killed $rc smoke
 for cfg in "develop D 0" "develop S 0" "develop D 2" "develop S 2" "develop G 0" "demosaic D 0" "apply D 0" "apply S 0"; do
   set -- $cfg
-  timeout -k 10 300 python bench.py --steps 20 --warmup 3 --workload $1 --params $2 --variant $3 --no-cpu-baseline >> $OUT/bench_variants.log 2>&1; rc=$?
+  timeout -k 10 300 python bench.py --steps 200 --warmup 20 --workload $1 --params $2 --variant $3 --no-cpu-baseline >> $OUT/bench_variants.log 2>&1; rc=$?
   stop_if_killed $rc "bench $cfg"
 done
 python - <<PY
@@ -23,7 +23,8 @@ for l in open("$OUT/bench_variants.log"):
 PY
 timeout -k 10 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; rc=$?; cat $OUT/bench_default.json; stop_if_killed $rc bench_default
 cd /tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"   # the default command (steps 400, warmup 50, preheat 200)
+P="python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --preheat 60 --no-cpu-baseline"   # counter passes: fewer launches
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_develop_D -o develop_D -- $B > $OUT/rocprof_stats.log 2>&1; rc=$?; stop_if_killed $rc rocprof_stats
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_develop_S -o develop_S -- $B --params S >> $OUT/rocprof_stats.log 2>&1; rc=$?; stop_if_killed $rc rocprof_stats
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_demosaic -o demosaic -- $B --workload demosaic >> $OUT/rocprof_stats.log 2>&1; rc=$?; stop_if_killed $rc rocprof_stats
@@ -35,7 +36,7 @@ for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_W
   i=$((i+1))
   for w in "develop D" "demosaic D"; do
     set -- $w
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pmc_$1_$i -o pmc -- $B --workload $1 --params $2 > $OUT/rocprof_pmc_$1_$i.log 2>&1; rc=$?; stop_if_killed $rc "pmc $i"
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pmc_$1_$i -o pmc -- $P --workload $1 --params $2 > $OUT/rocprof_pmc_$1_$i.log 2>&1; rc=$?; stop_if_killed $rc "pmc $i"
   done
 done
 ls $OUT | head -40

@@ -27,8 +27,9 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     lines = [f"# rocprofv3 summary — {label}", "",
-             "Source: `tools/gpu_pmc.sh` on one MI355X (gfx950), `bench.py --steps 10 --warmup 2` under "
-             "`rocprofv3 --kernel-trace --stats` and, separately, `--kernel-trace --pmc ...` passes.", ""]
+             "Source: `tools/gpu_pmc.sh` on one MI355X (gfx950): the default `bench.py` command (steps 400, warmup 50, "
+             "preheat 200; `--no-cpu-baseline`) under `rocprofv3 --kernel-trace --stats`, and, separately, "
+             "`--kernel-trace --pmc ...` passes of `bench.py --steps 50 --warmup 10 --preheat 60`.", ""]
 
     lines += ["## Kernel-trace stats (`--kernel-trace --stats`)", "",
               "| run | kernel | calls | avg µs | min µs | max µs |", "|---|---|---|---|---|---|"]
@@ -95,8 +96,9 @@ def main():
                     "per_pixel": a["SQ_INSTS_VALU"] * 64 / (mp * 1e6),
                     "kernel_us_under_pmc": avg_us,
                     "ns_per_instruction_per_simd": avg_us * 1e3 * 1024 / a["SQ_INSTS_VALU"],
-                    "note": "gfx950 issues one f32 add/mul/fma per ~1.1 ns per SIMD and one f64 / cvt / cndmask / cmp "
-                            "per ~1.8 ns (profiles/*_microbench.txt): at this instruction count the kernel is VALU-bound"}
+                    "note": ("gfx950 issues one f32 add/mul/fma per ~1.1 ns per SIMD and one f64 / cvt / cndmask / cmp "
+                             "per ~1.8 ns (profiles/*_microbench.txt): at this instruction count the kernel is VALU-bound")
+                    if w != "demosaic" else "instruction issue is a fraction of the kernel time: HBM/store-bound"}
         lines += ["Derived:", ""] + [f"- {d}" for d in der] + [""]
 
     for name in ("bench_default.json", "bench_variants.log", "microbench.txt"):
