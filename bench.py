@@ -7,9 +7,9 @@
 One step = one pass of the fused kernel (demosaic + black level/WB + camera matrix + the whole of
 wgsl main: tone, brightness curve, OKLCH curves, gamma) over one synthetic frame band that is already
 resident in HBM.  N = 1: BASELINE configs[2], the 6000x4000 frame.  N > 1: weak scaling — a
-6000 x (4000 N) frame cut into N row bands, one per rank; every step each rank develops the interior of
-its band on a side stream while it exchanges its 2-row Bayer halos with its neighbours (RCCL send/recv),
-then develops the 8 edge rows on either side (rawphotoforge_amd/tiles.py BandDeveloper).
+6000 x (4000 N) frame cut into N row bands, one per rank; every step each rank develops the interior of its
+band while a side stream exchanges its 2-row Bayer halos with its neighbours (RCCL send/recv) and develops the
+8 edge rows on either side (rawphotoforge_amd/tiles.py BandDeveloper).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, from HIP-event
 kernel times on the launch stream) and `cpu_baseline` (the oracle on the host cores, rank 0, N = 1).

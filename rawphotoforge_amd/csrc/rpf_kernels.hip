@@ -191,6 +191,9 @@ struct StreamArgs {
     RawParamsDev raw;
     DeviceEdit ed;
     uint32_t strips, seg_pairs, nitems;
+    // Items [0, tail_start) are dealt whole.  The last, incomplete round — fewer items than waves — is cut into
+    // single-pair sub-items: virtual item tail_start + t is pair (t % seg_pairs) of item tail_start + t / seg_pairs.
+    uint32_t tail_start, nvirt;
 };
 
 // One CFA row of a strip as the wavefront sees it: v = this lane's sample; p1 / p2 = the W+E sums at
@@ -244,11 +247,19 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
 
     // Every item (64 columns x 2*seg_pairs rows) costs the same number of instructions whatever the
     // image holds, so the items are dealt round-robin: wave-uniform loop, no queue.
-    for (uint32_t item = wave; item < a.nitems; item += nwaves) {
+    for (uint32_t vitem = wave; vitem < a.nvirt; vitem += nwaves) {
+        uint32_t item = vitem, sub = 0, sub_pairs = a.seg_pairs;
+        if (vitem >= a.tail_start) {
+            const uint32_t t = vitem - a.tail_start;
+            item = a.tail_start + t / a.seg_pairs;
+            sub = t - (item - a.tail_start) * a.seg_pairs;
+            sub_pairs = 1;
+        }
         const uint32_t seg = item / a.strips, strip = item - seg * a.strips;
         const int x0 = (int)strip * STRIP_W;
-        const int pair0 = (int)(seg * a.seg_pairs);
-        const int npairs = min((int)a.seg_pairs, total_pairs - pair0);
+        const int pair0 = (int)(seg * a.seg_pairs + sub);
+        const int npairs = min((int)sub_pairs, total_pairs - pair0);
+        if (npairs <= 0) continue;  // sub-item past the end of a ragged last segment
         const int xl = x0 + lane;  // this lane's column
         int gx = reflect101(xl, W);
         gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);  // columns past a ragged strip: unused
@@ -627,14 +638,21 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     if (e != hipSuccess) return e;
     constexpr uint32_t WPB = NT / 64;
     uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
+    a.tail_start = a.nvirt = a.nitems;
     if (MODE != MODE_DEMOSAIC) {
         // persistent workgroups (LDS tables staged once per workgroup), as many as are resident: the fused kernel
         // needs < 96 VGPRs, i.e. 5 waves per SIMD (variant 6: 4, for A/B); the 128-KiB curve in LDS limits that
-        // variant to one 1024-thread workgroup per CU.  (Cutting the last, incomplete round of items into
-        // single-pair sub-items was tried: no measurable change, profiles/r01_experiments.md.)
+        // variant to one 1024-thread workgroup per CU.
         uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
         const uint32_t cap = (uint32_t)cfg.num_cus * per_cu;
         if (grid > cap) grid = cap;
+        if (cfg.variant != 8) {  // tail balancing (variant 8: off, for A/B): -1 % (D) to -3 % (S) of kernel time
+            const uint32_t nwaves = grid * WPB;
+            if (a.nitems > nwaves) {  // a launch of at most one round gains nothing from four window start-ups per wave
+                a.tail_start = a.nitems / nwaves * nwaves;
+                a.nvirt = a.tail_start + (a.nitems - a.tail_start) * a.seg_pairs;
+            }
+        }
     } else if (blocks_per_cu) {
         const uint32_t cap = (uint32_t)cfg.num_cus * blocks_per_cu;
         if (grid > cap) grid = cap;

@@ -79,17 +79,21 @@ class BandDeveloper:
     """One rank's band of a row-tiled frame through the fused kernel, with the halo exchange hidden
     behind the interior rows.
 
-    Only the first/last EDGE rows of a band read halo rows; the interior never does.  Per step:
-    the interior tile is launched on a side stream, the 2-row halos are exchanged with the neighbours
-    (RCCL send/recv on the current stream), the two EDGE-row tiles run after the exchange, and the
-    streams are joined.  With world == 1 (or overlap=False) it is one launch on the current stream.
+    Only the first/last EDGE rows of a band read halo rows; the interior never does.  Per step (schedule
+    "side", the default): the interior tile is launched on the current stream; a side stream, gated on what the
+    current stream held before that launch, exchanges the 2-row halos with the neighbours (RCCL send/recv) and
+    runs the two EDGE-row tiles while the interior is still computing; the current stream then waits for the
+    side stream.  Measured on one MI355X without neighbours (tools/host_overhead.py): +1 % over a single
+    launch; "serial" (exchange started first, everything else on one stream) +6 %, because the two tiny edge
+    kernels then sit between consecutive interiors; "pipelined" (no per-step join: call join() before reading
+    the output) +0 %.  With world == 1 (or overlap=False) it is one launch.
     All three tiles are views of the same band / output buffers (rpf_dev_develop takes raw pointers).
     """
 
     EDGE = 8  # rows per edge tile = one work item of the kernel (64 columns x 8 rows)
 
     def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, rank=0, world=1, overlap=True,
-                 force_split=False):
+                 force_split=False, schedule="side"):
         import torch
 
         from .editor import PhotoEditor
@@ -109,44 +113,71 @@ class BandDeveloper:
             ed = PhotoEditor.for_tile(gpu, frame_width, frame_height, y0 + off, n)
             configure(ed)
             self.parts.append((off, n, ed))
-        self.side = torch.cuda.Stream() if self.split else None
+        self.schedule = schedule
+        self.side = torch.cuda.Stream() if self.split and schedule != "serial" else None
+        self._gate = torch.cuda.Event() if self.side is not None else None
+
+    def join(self):
+        """Make the current stream wait for edge tiles still running on the side stream ("pipelined" schedule)."""
+        if self.side is not None:
+            self._torch.cuda.current_stream().wait_stream(self.side)
 
     def step(self, band, out, out_format=0, bytes_per_px=16, exchange=True, events=None):
         """band: (rows + 4, W) 2-byte tensor with halo rows; out: rows x W pixels.  `events`: optional
         (start, end) CUDA events recorded around the dominant (interior / whole-band) launch."""
-        torch = self._torch
-        cur = torch.cuda.current_stream()
+        import torch.distributed as dist
+
+        cur = self._torch.cuda.current_stream()
+        stream = cur.cuda_stream
         bptr, optr = band.data_ptr(), out.data_ptr()
         row_in, row_out = self.w * 2, self.w * bytes_per_px
 
-        def launch(part, stream):
+        def launch(part):
             off, _, ed = part
-            ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, stream.cuda_stream)
+            ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, stream)
 
-        def exchange_now():
+        if self.side is not None:
+            # exchange + edge tiles on the side stream, gated on what the current stream held BEFORE the interior
+            torch = self._torch
+            self._gate.record(cur)
+            if events:
+                events[0].record(cur)
+            launch(self.parts[0])
+            if events:
+                events[1].record(cur)
+            self.side.wait_event(self._gate)
+            with torch.cuda.stream(self.side):
+                sstream = self.side.cuda_stream
+                if exchange and self.world > 1:
+                    key = (id(band), bptr)
+                    if self._ops_for != key:
+                        self._ops, self._ops_for = halo_ops(band, self.rank, self.world), key
+                    for r in dist.batch_isend_irecv(self._ops):
+                        r.wait()
+                for part in self.parts[1:]:
+                    off, _, ed = part
+                    ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, sstream)
+            if self.schedule != "pipelined":
+                cur.wait_stream(self.side)
+            return
+        reqs = ()
+        if exchange and self.world > 1:
             key = (id(band), bptr)
             if self._ops_for != key:
                 self._ops, self._ops_for = halo_ops(band, self.rank, self.world), key
-            exchange_halos(band, self.rank, self.world, ops=self._ops)
-
+            reqs = dist.batch_isend_irecv(self._ops)
+            if not self.split:
+                for r in reqs:
+                    r.wait()
+                reqs = ()
+        if events:
+            events[0].record(cur)
+        launch(self.parts[0])
+        if events:
+            events[1].record(cur)
         if not self.split:
-            if exchange and self.world > 1:
-                exchange_now()
-            if events:
-                events[0].record(cur)
-            launch(self.parts[0], cur)
-            if events:
-                events[1].record(cur)
             return
-        self.side.wait_stream(cur)  # the previous step's readers/writers of band/out are done
-        with torch.cuda.stream(self.side):
-            if events:
-                events[0].record(self.side)
-            launch(self.parts[0], self.side)
-            if events:
-                events[1].record(self.side)
-        if exchange and self.world > 1:
-            exchange_now()
-        launch(self.parts[1], cur)
-        launch(self.parts[2], cur)
-        cur.wait_stream(self.side)
+        for r in reqs:  # the current stream waits for the halo rows; the interior is already queued ahead of that
+            r.wait()
+        launch(self.parts[1])
+        launch(self.parts[2])

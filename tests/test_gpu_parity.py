@@ -302,7 +302,7 @@ def test_band_developer_overlap_split_equals_oracle(gpu):
                                  rank=rank, world=3, overlap=True)
         assert bd.split and [n for _, n, _ in bd.parts] == [rows - 16, 8, 8]
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        for _ in range(3):   # repeated steps: stream joins must order the reuse of band/out
+        for _ in range(3):   # repeated steps: stream order covers the reuse of band/out
             bd.step(band, out, R.OUT_RGBA_F32, 16, exchange=False, events=ev)
         torch.cuda.synchronize()
         assert ev[0].elapsed_time(ev[1]) > 0

@@ -13,8 +13,9 @@ gpu = R.GpuProcessor(0)
 W, H = 6000, 4000
 band = tiles.make_band_buffer(syn.bayer_uniform(H, W, seed=1), device="cuda")
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-for force in (False, True):
-    dev = tiles.BandDeveloper(gpu, W, H, 0, H, R.RawParams(**syn.RAW), lambda ed: syn.configure(ed, syn.PARAM_SETS["D"]), force_split=force)
+for force, sched in ((False, "serial"), (True, "serial"), (True, "side"), (True, "pipelined"), (False, "serial")):
+    dev = tiles.BandDeveloper(gpu, W, H, 0, H, R.RawParams(**syn.RAW), lambda ed: syn.configure(ed, syn.PARAM_SETS["D"]),
+                              force_split=force, schedule=sched)
     for _ in range(20):
         dev.step(band, out)
     torch.cuda.synchronize()
@@ -23,7 +24,8 @@ for force in (False, True):
     for _ in range(n):
         dev.step(band, out)
     t1 = time.perf_counter()
+    dev.join()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"{'three-launch overlap schedule' if force else 'single launch'}: host enqueue {1e6 * (t1 - t0) / n:.1f} us/step, "
+    print(f"{'three launches, schedule ' + sched if force else 'single launch'}: host enqueue {1e6 * (t1 - t0) / n:.1f} us/step, "
           f"GPU-complete {1e6 * (t2 - t0) / n:.1f} us/step")
