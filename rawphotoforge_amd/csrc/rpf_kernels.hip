@@ -629,21 +629,27 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     if (ed) a.ed = *ed;
     const uint32_t total_pairs = (g.rows + 1) / 2;
     a.strips = (g.width + STRIP_W - 1) / STRIP_W;
-    a.seg_pairs = seg_pairs ? seg_pairs : 4;  // 8 rows per item: measured best for both modes (profiles/r01_experiments.md)
-    const uint32_t segs = (total_pairs + a.seg_pairs - 1) / a.seg_pairs;
-    a.nitems = a.strips * segs;
+    constexpr uint32_t WPB = NT / 64;
     const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
     auto kernel = k_stream<NT, MODE, LDS_LUT, OUTFMT>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
-    constexpr uint32_t WPB = NT / 64;
+    // persistent workgroups for the fused kernel (LDS tables staged once per workgroup), as many as are resident: it
+    // needs < 96 VGPRs, i.e. 5 waves per SIMD (variant 6: 4, for A/B); the 128-KiB curve in LDS limits that variant
+    // to one 1024-thread workgroup per CU
+    const uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
+    const uint32_t cap_waves = (uint32_t)cfg.num_cus * per_cu * WPB;
+    auto items_for = [&](uint32_t sp) { return a.strips * ((total_pairs + sp - 1) / sp); };
+    // rows per item: 8 (demosaic: measured best; fused: enough waves for small frames); the fused kernel on a frame
+    // with more than two rounds of 32-row items (16-row with the curve in LDS: 4096 instead of 5120 waves) uses those
+    // (window start-up amortised: -1 % on 6000x4000)
+    a.seg_pairs = seg_pairs ? seg_pairs : 4;
+    const uint32_t big = LDS_LUT ? 8 : 16;
+    if (!seg_pairs && MODE != MODE_DEMOSAIC && cfg.variant != 9 && items_for(big) >= 2 * cap_waves) a.seg_pairs = big;
+    a.nitems = items_for(a.seg_pairs);
     uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
     a.tail_start = a.nvirt = a.nitems;
     if (MODE != MODE_DEMOSAIC) {
-        // persistent workgroups (LDS tables staged once per workgroup), as many as are resident: the fused kernel
-        // needs < 96 VGPRs, i.e. 5 waves per SIMD (variant 6: 4, for A/B); the 128-KiB curve in LDS limits that
-        // variant to one 1024-thread workgroup per CU.
-        uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
         const uint32_t cap = (uint32_t)cfg.num_cus * per_cu;
         if (grid > cap) grid = cap;
         if (cfg.variant != 8) {  // tail balancing (variant 8: off, for A/B): -1 % (D) to -3 % (S) of kernel time
