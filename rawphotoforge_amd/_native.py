@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librpf_hip.so")
+# RPF_HIP_LIB: load another build of the same library (A/B measurements of compiler options)
+LIB_PATH = os.environ.get("RPF_HIP_LIB") or os.path.join(_HERE, "librpf_hip.so")
 
 CURVE_RESOLUTION = 65536
 MAX_MASKS = 16
