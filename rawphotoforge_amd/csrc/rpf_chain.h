@@ -262,9 +262,11 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         const float l = RPF_F(0.4122214708) * r[n] + RPF_F(0.5363325363) * g[n] + RPF_F(0.0514459929) * b[n];
         const float mm = RPF_F(0.2119034982) * r[n] + RPF_F(0.6806995451) * g[n] + RPF_F(0.1073969566) * b[n];
         const float s = RPF_F(0.0883024619) * r[n] + RPF_F(0.2817188376) * g[n] + RPF_F(0.6299787005) * b[n];
-        const float lc = powc<POW_CBRT>(max0(l), T.cbrt);  // pow(max(lms, 0), 1/3), wgsl:67
-        const float mc = powc<POW_CBRT>(max0(mm), T.cbrt);
-        const float sc = powc<POW_CBRT>(max0(s), T.cbrt);
+        // pow(max(lms, 0), 1/3), wgsl:67.  The max is the identity here: r, g, b are k/65535 >= 0 after the
+        // brightness stage and every M1 coefficient is positive, so l, mm, s >= +0.
+        const float lc = powc<POW_CBRT>(l, T.cbrt);
+        const float mc = powc<POW_CBRT>(mm, T.cbrt);
+        const float sc = powc<POW_CBRT>(s, T.cbrt);
         L[n] = RPF_F(0.2104542553) * lc + RPF_F(0.7936177850) * mc + RPF_F(-0.0040720468) * sc;
         const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
         const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;

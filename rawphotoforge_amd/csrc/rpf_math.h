@@ -29,11 +29,9 @@ namespace rpf {
 // ---------------------------------------------------------------------------
 
 // x^c = 2^(e c) * r_j^(-c) * (1 + t)^c,  x = 2^e m,  t = m r_j - 1 (exact in binary64)
-#define RPF_POW_EMIN (-160)  // covers every binary32 exponent, subnormals included (2^-149)
-#define RPF_POW_ECNT 288
 struct PowTable {
-    double E[RPF_POW_ECNT];  // E[e - EMIN] = 2^(e c)
-    double TR[128][2];       // TR[j] = { r_j^(-c), r_j },  j = top 7 mantissa bits
+    double E[256];       // E[b] = 2^((b - 127) c) for the biased binary32 exponent b; E[0] = 0 (x = 0)
+    double TR[128][2];   // TR[j] = { r_j^(-c), r_j },  j = top 7 mantissa bits
 };
 
 // cos/sin of k * K_HUE_STEP split as k = 256 k1 + k0
@@ -110,26 +108,26 @@ RPF_HD float div_by_const(float x, float d, float rd)
     return q;
 }
 
-// Correctly rounded x^c for x >= 0 (c fixed by KIND).  Exhaustively equal to the oracle's
-// cr_powf on [2^-21, 1.25) for cbrt and [2^-9, 2^3) for gamma; same algorithm (rel. error
-// < 2^-50 before the single rounding) on the rest of the binary32 range.
-// Finite x >= 0 only.  x = 0 has a zero exponent field, lands on table entry 0 (below every binary32
-// exponent) which holds 0.0, so pow(0, c) = 0 falls out of the same multiplications with no select;
-// a negative x returns |x|^c (the chain never uses that value: wgsl:67 takes max(x, 0), wgsl:98 the
-// linear branch).
+// Correctly rounded x^c for normal x >= 0 (c fixed by KIND).  Exhaustively equal to the oracle's cr_powf on
+// [2^-21, 1.25) for cbrt, [2^-9, 2^3) for gamma and [2^-4, 2) for the legacy decode; same algorithm (rel. error
+// < 2^-50 before the single rounding) on every other normal binary32.
+// The exponent and the table indices are taken straight from the binary32 bit pattern with shifts and masks
+// (full-rate on gfx950; the v_bfe / v_lshl_add forms are half-rate), the sign bit is masked off (a negative x
+// returns |x|^c: the chain never uses that value — wgsl:67 takes max(x, 0), wgsl:98 the linear branch).
+// x = 0 has exponent field 0, whose table entry is 0.0, so pow(0, c) = 0 falls out of the same multiplications
+// with no select; a SUBNORMAL x also returns 0.  The chain cannot produce one where it matters: cube-root
+// inputs are 0 or >= 7e-7 (M1 times channels that are multiples of 1/65535), and below 0.0031308 the gamma
+// stage takes its linear branch.
 template <int KIND, class TabT>
 RPF_HD float powc(float x, const TabT& T)
 {
-    const double xd = (double)x;
-    const uint64_t u = d2u(xd);
-    const uint32_t hi = (uint32_t)(u >> 32);
-    const uint32_t ebits = (hi >> 20) & 0x7ffu;
-    const uint32_t j = (hi >> 13) & 127u;
-    int ei = (int)ebits - (1023 + RPF_POW_EMIN);
-    ei = ei < 0 ? 0 : ei;  // finite binary32 never exceeds the table (2^127 -> entry 287)
-    const double m = hilo2d((hi & 0x000fffffu) | 0x3ff00000u, (uint32_t)u);
-    const double r = T.TR[j][1];
-    const double tj = T.TR[j][0];
+    const uint32_t b = f2bits(x);
+    const uint32_t eoff = (b >> 20) & 0x7f8u;  // biased exponent * 8: byte offset into E
+    const uint32_t joff = (b >> 12) & 0x7f0u;  // top 7 mantissa bits * 16: byte offset into TR
+    const double m = (double)bits2f((b & 0x007fffffu) | 0x3f800000u);  // significand in [1, 2), exact
+    const double* tr = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.TR[0][0]) + joff);
+    const double e2 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.E[0]) + eoff);
+    const double tj = tr[0], r = tr[1];
     const double t = __builtin_fma(m, r, -1.0);
     using K = PowCoef<KIND>;
     double p = __builtin_fma(t, K::c5, K::c4);
@@ -137,7 +135,7 @@ RPF_HD float powc(float x, const TabT& T)
     p = __builtin_fma(t, p, K::c2);
     p = __builtin_fma(t, p, K::c1);
     p = __builtin_fma(t, p, 1.0);
-    return (float)((T.E[ei] * tj) * p);
+    return (float)((e2 * tj) * p);
 }
 
 // atan(q) = q + q^3 P(q^2), |q| <= tan(pi/8); rel. error 2^-52.7 (tools/gen_math_consts.py)

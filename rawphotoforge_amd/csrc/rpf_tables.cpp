@@ -9,9 +9,8 @@ namespace rpf {
 static void build_pow(PowTable& P, float cf)
 {
     const long double c = (long double)cf;
-    for (int e = RPF_POW_EMIN; e < RPF_POW_EMIN + RPF_POW_ECNT; ++e)
-        P.E[e - RPF_POW_EMIN] = (double)powl(2.0L, (long double)e * c);
-    P.E[0] = 0.0;  // 2^-160 is below every binary32: entry 0 is only ever reached by x = 0 (see powc)
+    for (int b = 1; b < 256; ++b) P.E[b] = (double)powl(2.0L, (long double)(b - 127) * c);
+    P.E[0] = 0.0;  // exponent field 0: x = 0 (and subnormals, see powc)
     for (int j = 0; j < 128; ++j) {
         const long double mid = 1.0L + ((long double)j + 0.5L) / 128.0L;
         // r_j: reciprocal of the bin centre on a 2^-16 grid, so m * r_j is exact in binary64

