@@ -17,7 +17,7 @@
 //     the strip's apron (64 loaded columns -> 60 outputs).
 //   * a vertical pixel pair always holds one R/B site and one G site, so both demosaic formula sets run
 //     without divergence, and the pair goes through the edit chain in lockstep (rpf_chain.h);
-//   * the transcendental tables (17 KiB) and, when it is not the identity, the 65536-entry brightness
+//   * the transcendental tables (28 KiB) and, when it is not the identity, the 65536-entry brightness
 //     curve (u16, 128 KiB) are staged in LDS once per workgroup, so curve gathers never leave the CU;
 //   * every store is a global_store_dwordx4, 960 B contiguous per wave-instruction.
 // Pointwise/stencil path: HBM-bound by construction, no MFMA.
@@ -708,9 +708,8 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
                               const DeviceEdit& ed, void* d_out, hipStream_t s)
 {
     const bool lut = needs_lds_lut(ed);
-    if (cfg.variant == 1)  // LDS-tile front end
-        return lut ? run_tile<512, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, 1, s)
-                   : run_tile<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, 2, s);
+    if (cfg.variant == 1)  // LDS-tile front end (its tile + the tables + a 128-KiB curve exceed the LDS: curve from L2)
+        return run_tile<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, 2, s);
     if (cfg.variant == 2)  // streaming, 512-thread workgroups
         return lut ? run_stream<512, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                    : run_stream<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);

@@ -31,7 +31,10 @@ namespace rpf {
 // x^c = 2^(e c) * r_j^(-c) * (1 + t)^c,  x = 2^e m,  t = m r_j - 1 (exact in binary64)
 struct PowTable {
     double E[256];       // E[b] = 2^((b - 127) c) for the biased binary32 exponent b; E[0] = 0 (x = 0)
-    double TR[128][2];   // TR[j] = { r_j^(-c), r_j },  j = top 7 mantissa bits
+#ifndef RPF_POW_BITS
+#define RPF_POW_BITS 9
+#endif
+    double TR[1 << RPF_POW_BITS][2];   // TR[j] = { r_j^(-c), r_j },  j = top 9 mantissa bits: |t| <= 2^-10, degree 4 suffices
 };
 
 // cos/sin of k * K_HUE_STEP split as k = 256 k1 + k0
@@ -123,15 +126,19 @@ RPF_HD float powc(float x, const TabT& T)
 {
     const uint32_t b = f2bits(x);
     const uint32_t eoff = (b >> 20) & 0x7f8u;  // biased exponent * 8: byte offset into E
-    const uint32_t joff = (b >> 12) & 0x7f0u;  // top 7 mantissa bits * 16: byte offset into TR
+    const uint32_t joff = (b >> (19 - RPF_POW_BITS)) & (((1u << RPF_POW_BITS) - 1u) << 4);  // top 9 mantissa bits * 16: byte offset into TR
     const double m = (double)bits2f((b & 0x007fffffu) | 0x3f800000u);  // significand in [1, 2), exact
     const double* tr = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.TR[0][0]) + joff);
     const double e2 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.E[0]) + eoff);
     const double tj = tr[0], r = tr[1];
     const double t = __builtin_fma(m, r, -1.0);
     using K = PowCoef<KIND>;
+#if RPF_POW_BITS >= 9
+    double p = __builtin_fma(t, K::c4, K::c3);  // c5 t^5 < 2^-55: dropped
+#else
     double p = __builtin_fma(t, K::c5, K::c4);
     p = __builtin_fma(t, p, K::c3);
+#endif
     p = __builtin_fma(t, p, K::c2);
     p = __builtin_fma(t, p, K::c1);
     p = __builtin_fma(t, p, 1.0);

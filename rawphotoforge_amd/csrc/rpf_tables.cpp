@@ -11,8 +11,9 @@ static void build_pow(PowTable& P, float cf)
     const long double c = (long double)cf;
     for (int b = 1; b < 256; ++b) P.E[b] = (double)powl(2.0L, (long double)(b - 127) * c);
     P.E[0] = 0.0;  // exponent field 0: x = 0 (and subnormals, see powc)
-    for (int j = 0; j < 128; ++j) {
-        const long double mid = 1.0L + ((long double)j + 0.5L) / 128.0L;
+    const int nbins = 1 << RPF_POW_BITS;
+    for (int j = 0; j < nbins; ++j) {
+        const long double mid = 1.0L + ((long double)j + 0.5L) / (long double)nbins;
         // r_j: reciprocal of the bin centre on a 2^-16 grid, so m * r_j is exact in binary64
         const double r = (double)(roundl((1.0L / mid) * 65536.0L) / 65536.0L);
         P.TR[j][1] = r;
