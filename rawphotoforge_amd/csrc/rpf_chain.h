@@ -228,13 +228,18 @@ RPF_HD void mask_rgb_stage(const MaskParams& P, uint32_t m, const Luts& luts, fl
         }
         x = clamp01(x); y = clamp01(y); z = clamp01(z);
         // brightness curve, wgsl:293-305
-        uint32_t xu = (uint32_t)(x * 65535.0f), yu = (uint32_t)(y * 65535.0f), zu = (uint32_t)(z * 65535.0f);
+        // f32(u32(v)) for v in [0, 65535] is trunc(v): with the identity curve no integer is needed at all
+        float xk = x * 65535.0f, yk = y * 65535.0f, zk = z * 65535.0f;
         if (!(P.flags & MF_BRIGHT_IDENTITY)) {
-            xu = luts.brightness(m, xu); yu = luts.brightness(m, yu); zu = luts.brightness(m, zu);
+            xk = (float)luts.brightness(m, (uint32_t)xk);
+            yk = (float)luts.brightness(m, (uint32_t)yk);
+            zk = (float)luts.brightness(m, (uint32_t)zk);
+        } else {
+            xk = __builtin_truncf(xk); yk = __builtin_truncf(yk); zk = __builtin_truncf(zk);
         }
-        x = div_u16_by(xu, 65535.0f, inv65535);
-        y = div_u16_by(yu, 65535.0f, inv65535);
-        z = div_u16_by(zu, 65535.0f, inv65535);
+        x = div_u16f_by(xk, 65535.0f, inv65535);
+        y = div_u16f_by(yk, 65535.0f, inv65535);
+        z = div_u16f_by(zk, 65535.0f, inv65535);
         const bool on = act ? act[n] : true;
         r[n] = on ? x : r[n]; g[n] = on ? y : g[n]; b[n] = on ? z : b[n];
     }

@@ -89,13 +89,13 @@ RPF_HD double hilo2d(uint32_t hi, uint32_t lo) { return u2d(((uint64_t)hi << 32)
 // f32(k) / d for integer k in [0, 65535] and d in {65535, 32767.5}: q = k*r, one
 // fma residual, one fma correction.  Equal to the IEEE quotient for every k
 // (checked exhaustively in tests/test_math_exhaustive.py).  wgsl:303-305, 328-330.
-RPF_HD float div_u16_by(uint32_t k, float d, float rd)
+RPF_HD float div_u16f_by(float kf, float d, float rd)  // kf: an integer in [0, 65535] held as binary32
 {
-    const float kf = (float)k;
     const float q0 = kf * rd;
     const float e = __builtin_fmaf(-q0, d, kf);
     return __builtin_fmaf(e, rd, q0);
 }
+RPF_HD float div_u16_by(uint32_t k, float d, float rd) { return div_u16f_by((float)k, d, rd); }
 
 // x / d for a constant d: Markstein's sequence (q = RN(x rd), r = fma(-q, d, x) exact,
 // q' = RN(q + r rd)) is the correctly rounded quotient when rd = RN(1/d) and d's significand
