@@ -89,6 +89,17 @@ F32_KERNEL(k_readlane, "v_readlane_b32 s20, %0, 3", "v_readlane_b32 s21, %1, 3",
 F32_KERNEL(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %0", "v_cvt_f32_u32 %1, %1", "v_cvt_f32_u32 %2, %2", "v_cvt_f32_u32 %3, %3",
            "v_cvt_f32_u32 %4, %4", "v_cvt_f32_u32 %5, %5", "v_cvt_f32_u32 %6, %6", "v_cvt_f32_u32 %7, %7")
 
+F32_KERNEL(k_cnd_e32, "v_cndmask_b32_e32 %0, %8, %0, vcc", "v_cndmask_b32_e32 %1, %8, %1, vcc", "v_cndmask_b32_e32 %2, %8, %2, vcc", "v_cndmask_b32_e32 %3, %8, %3, vcc", "v_cndmask_b32_e32 %4, %8, %4, vcc", "v_cndmask_b32_e32 %5, %8, %5, vcc", "v_cndmask_b32_e32 %6, %8, %6, vcc", "v_cndmask_b32_e32 %7, %8, %7, vcc")
+F32_KERNEL(k_cnd_e64vcc, "v_cndmask_b32_e64 %0, %8, %0, vcc", "v_cndmask_b32_e64 %1, %8, %1, vcc", "v_cndmask_b32_e64 %2, %8, %2, vcc", "v_cndmask_b32_e64 %3, %8, %3, vcc", "v_cndmask_b32_e64 %4, %8, %4, vcc", "v_cndmask_b32_e64 %5, %8, %5, vcc", "v_cndmask_b32_e64 %6, %8, %6, vcc", "v_cndmask_b32_e64 %7, %8, %7, vcc")
+F32_KERNEL(k_cmp_cnd_vcc, "v_cmp_lt_f32_e32 vcc, %8, %0\nv_cndmask_b32_e32 %0, %9, %0, vcc", "v_cmp_lt_f32_e32 vcc, %8, %1\nv_cndmask_b32_e32 %1, %9, %1, vcc", "v_cmp_lt_f32_e32 vcc, %8, %2\nv_cndmask_b32_e32 %2, %9, %2, vcc", "v_cmp_lt_f32_e32 vcc, %8, %3\nv_cndmask_b32_e32 %3, %9, %3, vcc", "v_cmp_lt_f32_e32 vcc, %8, %4\nv_cndmask_b32_e32 %4, %9, %4, vcc", "v_cmp_lt_f32_e32 vcc, %8, %5\nv_cndmask_b32_e32 %5, %9, %5, vcc", "v_cmp_lt_f32_e32 vcc, %8, %6\nv_cndmask_b32_e32 %6, %9, %6, vcc", "v_cmp_lt_f32_e32 vcc, %8, %7\nv_cndmask_b32_e32 %7, %9, %7, vcc")
+F32_KERNEL(k_cmp_cnd_sgpr, "v_cmp_lt_f32_e64 s[20:21], %8, %0\nv_cndmask_b32_e64 %0, %9, %0, s[20:21]", "v_cmp_lt_f32_e64 s[20:21], %8, %1\nv_cndmask_b32_e64 %1, %9, %1, s[20:21]", "v_cmp_lt_f32_e64 s[20:21], %8, %2\nv_cndmask_b32_e64 %2, %9, %2, s[20:21]", "v_cmp_lt_f32_e64 s[20:21], %8, %3\nv_cndmask_b32_e64 %3, %9, %3, s[20:21]", "v_cmp_lt_f32_e64 s[20:21], %8, %4\nv_cndmask_b32_e64 %4, %9, %4, s[20:21]", "v_cmp_lt_f32_e64 s[20:21], %8, %5\nv_cndmask_b32_e64 %5, %9, %5, s[20:21]", "v_cmp_lt_f32_e64 s[20:21], %8, %6\nv_cndmask_b32_e64 %6, %9, %6, s[20:21]", "v_cmp_lt_f32_e64 s[20:21], %8, %7\nv_cndmask_b32_e64 %7, %9, %7, s[20:21]")
+F32_KERNEL(k_trunc_f32, "v_trunc_f32 %0, %0", "v_trunc_f32 %1, %1", "v_trunc_f32 %2, %2", "v_trunc_f32 %3, %3", "v_trunc_f32 %4, %4", "v_trunc_f32 %5, %5", "v_trunc_f32 %6, %6", "v_trunc_f32 %7, %7")
+F32_KERNEL(k_and_or, "v_and_or_b32 %0, %0, %8, %9", "v_and_or_b32 %1, %1, %8, %9", "v_and_or_b32 %2, %2, %8, %9", "v_and_or_b32 %3, %3, %8, %9", "v_and_or_b32 %4, %4, %8, %9", "v_and_or_b32 %5, %5, %8, %9", "v_and_or_b32 %6, %6, %8, %9", "v_and_or_b32 %7, %7, %8, %9")
+F32_KERNEL(k_min_u32, "v_min_u32 %0, %8, %0", "v_min_u32 %1, %8, %1", "v_min_u32 %2, %8, %2", "v_min_u32 %3, %8, %3", "v_min_u32 %4, %8, %4", "v_min_u32 %5, %8, %5", "v_min_u32 %6, %8, %6", "v_min_u32 %7, %8, %7")
+F32_KERNEL(k_sub_f32_lit, "v_sub_f32 %0, 0x3f9e3779, %0", "v_sub_f32 %1, 0x3f9e3779, %1", "v_sub_f32 %2, 0x3f9e3779, %2", "v_sub_f32 %3, 0x3f9e3779, %3", "v_sub_f32 %4, 0x3f9e3779, %4", "v_sub_f32 %5, 0x3f9e3779, %5", "v_sub_f32 %6, 0x3f9e3779, %6", "v_sub_f32 %7, 0x3f9e3779, %7")
+F32_KERNEL(k_fmac_f32, "v_fmac_f32 %0, %8, %9", "v_fmac_f32 %1, %8, %9", "v_fmac_f32 %2, %8, %9", "v_fmac_f32 %3, %8, %9", "v_fmac_f32 %4, %8, %9", "v_fmac_f32 %5, %8, %9", "v_fmac_f32 %6, %8, %9", "v_fmac_f32 %7, %8, %9")
+F32_KERNEL(k_mad_lit, "v_fmaak_f32 %0, %8, %0, 0x3f9e3779", "v_fmaak_f32 %1, %8, %1, 0x3f9e3779", "v_fmaak_f32 %2, %8, %2, 0x3f9e3779", "v_fmaak_f32 %3, %8, %3, 0x3f9e3779", "v_fmaak_f32 %4, %8, %4, 0x3f9e3779", "v_fmaak_f32 %5, %8, %5, 0x3f9e3779", "v_fmaak_f32 %6, %8, %6, 0x3f9e3779", "v_fmaak_f32 %7, %8, %7, 0x3f9e3779")
+
 // 64-bit operand kernels: accumulators are doubles / float2
 #define F64_KERNEL(NAME, T, INIT, I0, I1, I2, I3, I4, I5, I6, I7)                                           \
     __global__ void NAME(float* out, long long* cyc, T x, T y)                                               \
@@ -119,6 +130,12 @@ F64_KERNEL(k_mul_f64, double, DINIT, "v_mul_f64 %0, %8, %0", "v_mul_f64 %1, %8, 
 F64_KERNEL(k_add_f64, double, DINIT, "v_add_f64 %0, %8, %0", "v_add_f64 %1, %8, %1", "v_add_f64 %2, %8, %2",
            "v_add_f64 %3, %8, %3", "v_add_f64 %4, %8, %4", "v_add_f64 %5, %8, %5", "v_add_f64 %6, %8, %6",
            "v_add_f64 %7, %8, %7")
+F64_KERNEL(k_fma_f64_sgpr, double, DINIT, "v_fma_f64 %0, s[20:21], %9, %0", "v_fma_f64 %1, s[20:21], %9, %1", "v_fma_f64 %2, s[20:21], %9, %2",
+           "v_fma_f64 %3, s[20:21], %9, %3", "v_fma_f64 %4, s[20:21], %9, %4", "v_fma_f64 %5, s[20:21], %9, %5",
+           "v_fma_f64 %6, s[20:21], %9, %6", "v_fma_f64 %7, s[20:21], %9, %7")
+F64_KERNEL(k_lshl_add_u64, double, DINIT, "v_lshl_add_u64 %0, %0, 1, %8", "v_lshl_add_u64 %1, %1, 1, %8", "v_lshl_add_u64 %2, %2, 1, %8",
+           "v_lshl_add_u64 %3, %3, 1, %8", "v_lshl_add_u64 %4, %4, 1, %8", "v_lshl_add_u64 %5, %5, 1, %8",
+           "v_lshl_add_u64 %6, %6, 1, %8", "v_lshl_add_u64 %7, %7, 1, %8")
 #undef SUM8
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define PINIT(k) (f2{(float)threadIdx.x + k, (float)threadIdx.x - k})
@@ -223,7 +240,7 @@ __global__ void k_clock(long long* o)
     if (threadIdx.x == 0) { o[0] = t1 - t0; o[1] = r1 - r0; o[2] = (long long)a; }
 }
 
-int main()
+int main(int argc, char**)
 {
     long long* dclk; long long hclk[3];
     (void)hipMalloc(&dclk, 24);
@@ -231,6 +248,23 @@ int main()
     (void)hipMemcpy(hclk, dclk, 24, hipMemcpyDeviceToHost);
     printf("s_memtime ticks per s_memrealtime tick (100 MHz): %.3f -> s_memtime at %.1f MHz\n", (double)hclk[0] / hclk[1], 100.0 * hclk[0] / hclk[1]);
     printf("per wave-instruction per SIMD: s_memtime ticks | wall ns, at waves/SIMD = 1, 2, 4, 8\n");
+    if (argc > 1) {   // second batch (r01 late): forms of select / compare, a few more classes
+        run("cnd e32 vcc", k_cnd_e32, 0, 1.0001f, 0.5f);
+        run("cnd e64 vcc", k_cnd_e64vcc, 0, 1.0001f, 0.5f);
+        run("cnd e64 sgpr", k_cndmask, 0, 1.0001f, 0.5f);
+        run("cmp+cnd vcc x2", k_cmp_cnd_vcc, 0, 1.0001f, 0.5f);
+        run("cmp+cnd sgpr x2", k_cmp_cnd_sgpr, 0, 1.0001f, 0.5f);
+        run("v_trunc_f32", k_trunc_f32, 0, 1.0001f, 0.5f);
+        run("v_and_or_b32", k_and_or, 0, 1.0001f, 0.5f);
+        run("v_min_u32", k_min_u32, 0, 1.0001f, 0.5f);
+        run("v_sub_f32 lit", k_sub_f32_lit, 0, 1.0001f, 0.5f);
+        run("v_fmac_f32", k_fmac_f32, 0, 1.0001f, 0.5f);
+        run("v_fmaak_f32", k_mad_lit, 0, 1.0001f, 0.5f);
+        run("v_fma_f64 sgpr", k_fma_f64_sgpr, 0, 1.0001, 0.5);
+        run("v_fma_f64", k_fma_f64, 0, 1.0001, 0.5);
+        run("v_lshl_add_u64", k_lshl_add_u64, 0, 1.0001, 0.5);
+        return 0;
+    }
     run("v_fma_f32", k_fma_f32, 0, 1.0001f, 0.5f);
     run("v_mul_f32", k_mul_f32, 0, 1.0001f, 0.5f);
     run("v_add_f32", k_add_f32, 0, 1.0001f, 0.5f);
