@@ -245,11 +245,17 @@ RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
     uint32_t eb = f2bits(mx) >> 23;
     eb = eb > 253u ? 253u : eb;
     const float sc = bits2f((254u - eb) << 23);
-    const float mxs = mx * sc, mns = mn * sc;
+    // mx == 0 (a = b = 0): the floor keeps the quotient at 0 instead of 0 * inf — straight-line code on purpose:
+    // written as a select around the table read, the compiler turns it into a branch per pixel with the
+    // gather and its wait inside, which serialises the pair and exposes the whole L2 latency
+    const float mns = mn * sc;
 #if defined(__HIP_DEVICE_COMPILE__)
+    const float mxs = __builtin_fmaxf(mx * sc, 0x1p-100f);
     const float q = mns * __builtin_amdgcn_rcpf(mxs);
 #else
-    const float q = mxs > 0.0f ? mns / mxs : 0.0f;
+    const float mxs0 = mx * sc;
+    const float mxs = mxs0 > 0x1p-100f ? mxs0 : 0x1p-100f;
+    const float q = mns / mxs;
 #endif
     // atan(q) * 65535 / (2 pi) for q in [0, 1], |error| < 0.12 index units (tools/gen_math_consts.py)
     const float z = q * q;
@@ -264,10 +270,11 @@ RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
     const uint32_t j = (uint32_t)(v + 0.5f) & 0xffffu;
     const HueBound bd = hb[j];
     const double d = __builtin_fma((double)y, bd.c, -((double)x * bd.s));
-    uint32_t k = (j - (d >= 0.0 ? 0u : 1u)) & 0xffffu;
-    // atan2(+-0, +0) = +-0 -> 0;  atan2(+-0, -0) = +-pi -> 32767
-    k = mx == 0.0f ? ((f2bits(x) >> 31) ? 32767u : 0u) : k;
-    return k;
+    const uint32_t k = (j - (d >= 0.0 ? 0u : 1u)) & 0xffffu;
+    // a = b = 0 arrives here as j = 0, d = +-0, k = 0, which is atan2(+-0, +0) = +-0 -> 0;
+    // atan2(+-0, -0) = +-pi -> 32767 is OR-ed in (k is 0 in that case)
+    const uint32_t zero_negx = (mx == 0.0f) ? ((f2bits(x) >> 31) * 32767u) : 0u;
+    return k | zero_negx;
 }
 
 // pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171):
