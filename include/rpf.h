@@ -238,7 +238,8 @@ int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_edito
 /* Kernel variant selection for A/B measurements (bench.py --variant); 0 = shipped configuration.
  * fused develop: 1 = LDS-tile front end (first design), 2 = 512-thread workgroups, 3 = pixel pair sequentially,
  * 6 = 4 instead of 5 waves per SIMD, 7 = the general multi-mask kernel also when only "main" exists,
- * 8 = no splitting of the last, incomplete round of work items, 9 = 8-row instead of 32-/16-row work items;
+ * 8 = no splitting of the last, incomplete round of work items, 9 = 8-row instead of 32-/16-row work items,
+ * 10 = brightness curve gathered from L2 instead of staged in LDS;
  * demosaic: 1 = LDS-tile front end, 3 = ordinary (not nontemporal) stores, 4 = 16-row items.  Same output bits. */
 int rpf_set_kernel_variant(rpf_processor* p, int variant);
 

@@ -716,7 +716,7 @@ template <int OUTFMT>
 static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                               const DeviceEdit& ed, void* d_out, hipStream_t s)
 {
-    const bool lut = needs_lds_lut(ed);
+    const bool lut = needs_lds_lut(ed) && cfg.variant != 10;  // variant 10 (A/B): the brightness curve gathered from L2
     if (cfg.variant == 1)  // LDS-tile front end (its tile + the tables + a 128-KiB curve exceed the LDS: curve from L2)
         return run_tile<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, 2, s);
     if (cfg.variant == 2)  // streaming, 512-thread workgroups
