@@ -163,6 +163,14 @@ void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint3
 }
 
 // ---- host state machine under sanitizers (tools/sanitize_cpu.sh) ---------------------------------
+extern "C" {
+// the PPM header grammar of the C ABI (rpf_host.h), for the sanitizer run and the no-GPU tests
+int twin_ppm_header(const uint8_t* file, size_t len, uint32_t* w, uint32_t* h, size_t* off)
+{
+    return rpf::ppm16_parse_header(file, len, w, h, off).code;
+}
+}
+
 extern "C" int twin_state_exercise(void)
 {
     rpf::EditState st(7, 5);

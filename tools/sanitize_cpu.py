@@ -33,5 +33,27 @@ for bits in (10, 12, 14, 16):
 O.resize_long_edge(rng.random((33, 5, 3), dtype=np.float32), 7)
 O.legacy_tone_lut(0.5, 20, 30, -20, 5, -5)
 O.legacy_apply_gamma(rng.random(1000, dtype=np.float32), (2.222, 4.5))
+# later additions: hue index (table gather), legacy flavour, PPM header grammar on hostile input
+tw, orc = util.twin(), O.lib()
+n = 200_000
+y = (rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 2, n)).astype(np.float32)
+x = (rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 2, n)).astype(np.float32)
+y[:8] = [0, -0.0, 0, -0.0, 1e-45, -1e-45, 3e38, -3e38]
+x[:8] = [0, 0, -0.0, -0.0, 1, -1, 3e38, 1e-45]
+a, b = np.empty(n, np.uint32), np.empty(n, np.uint32)
+tw.twin_hue_index_many(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_size_t(n), a.ctypes.data_as(C.c_void_p))
+orc.orc_hue_index_many(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_size_t(n), b.ctypes.data_as(C.c_void_p))
+assert int((a != b).sum()) <= 1          # the documented (-3.5 * 2^-149, 0) corner is in the list above
+for v in (0.0, 0.04045, 0.5, 1.0, 1.7):
+    tw.twin_srgb_to_linear(v), tw.twin_pow_4(v)
+img = rng.random((9, 11, 4), dtype=np.float32)
+O.apply(img, [O.EditParameters(vignette=-40, lens_distortion=30)], legacy="encoded")
+for blob in (b"", b"P6", b"P6\n", b"P6\n3 2\n65535\n", b"P6\n99999999999 2\n65535\n", b"P6\n3 2\n65535\n" + bytes(36),
+             b"\n\n\n\n", b"P6\n" + b"9" * 200 + b"\n1\n"):
+    O.ppm16_header(blob)
+    arr = np.frombuffer(blob + b"\0", np.uint8)   # +1: a non-empty buffer to point at; len excludes it
+    w_, h_, o_ = C.c_uint32(), C.c_uint32(), C.c_size_t()
+    rc = tw.twin_ppm_header(arr.ctypes.data_as(C.c_void_p), C.c_size_t(len(blob)), C.byref(w_), C.byref(h_), C.byref(o_))
+    assert (rc == 0) == (O.ppm16_header(blob)[0] == 0)
 assert util.twin().twin_state_exercise() == 0
 print("sanitizer run complete: no ASan / UBSan report")
