@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 W, H = 6000, 4000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PX = {"develop": 18, "demosaic": 18, "apply": 32,   # u16 in + RGBA32F out
-                "unpack": 3.5}                                  # 12-bit packed in (1.5 B) + u16 out
+                "unpack": 3.5,                                  # 12-bit packed in (1.5 B) + u16 out
+                "develop_packed": 17.75}                        # 14-bit packed in (1.75 B) + RGBA32F out
 
 
 def main():
@@ -38,7 +39,7 @@ def main():
                     help="untimed steps before the W warmup steps (same count on every rank): an idle MI355X needs "
                          "~50 launches (15 ms) to reach its steady clocks, and steady state is what a production "
                          "service sees (profiles/r01_experiments.md)")
-    ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply", "unpack"])
+    ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply", "unpack", "develop_packed"])
     ap.add_argument("--params", default="D", choices=["D", "S", "G"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
@@ -71,6 +72,7 @@ def main():
     frame_h = H * world
     y0, rows = rank * H, H
     praw = R.RawParams(**syn.RAW)
+    praw_c = praw.to_c()
     spec = syn.PARAM_SETS[args.params]
     gen = syn.bayer_uniform if args.data == "U" else syn.bayer_natural
     cfa = gen(rows, W, seed=20260630 + rank)          # this rank's band (rank 0 at N=1: THE frame)
@@ -91,8 +93,12 @@ def main():
 
     packed = None
     if args.workload == "unpack":   # the integer stage in front: 12-bit MSB-first packed -> the band buffer's own rows
-        bits16 = np.unpackbits((cfa & 0x0FFF).astype(">u2").view(np.uint8).reshape(rows, W, 2), axis=2)[:, :, 4:]
-        packed = torch.from_numpy(np.packbits(bits16.reshape(rows, W * 12), axis=1)).cuda()
+        packed = torch.from_numpy(syn.pack_msb(cfa & 0x0FFF, 12)).cuda()
+    packed_band, packed_stride = None, 0
+    if args.workload == "develop_packed":   # the same frame as "develop" (14-bit values), bit-packed incl. halo rows
+        host_packed = syn.pack_msb(band.cpu().numpy().view(np.uint16), 14)
+        packed_stride = host_packed.shape[1]
+        packed_band = torch.from_numpy(host_packed).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -103,7 +109,9 @@ def main():
         tiles.exchange_halos(band, rank, world)          # no-op at N = 1
         if i is not None:
             ev[i][0].record()
-        if args.workload == "unpack":
+        if args.workload == "develop_packed":
+            ed.dev_develop_packed(packed_band.data_ptr(), packed_stride, 14, praw_c, out.data_ptr(), R.OUT_RGBA_F32, stream)
+        elif args.workload == "unpack":
             R.dev_unpack_bayer(gpu, packed.data_ptr(), packed.shape[1], W, rows, 12, band[2:].data_ptr(), stream)
         elif args.workload == "demosaic":
             R.dev_demosaic(gpu, band.data_ptr(), praw, W, frame_h, y0, rows, out.data_ptr(), stream)

@@ -229,6 +229,11 @@ int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_para
  * via rpf_editor_create_for_tile. */
 int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* raw, void* d_out, int out_format,
                     void* stream);
+/* The same with the integer unpack folded into the kernel's row loads: d_packed holds the band's (rows + 4) rows in the
+ * packed layout of rpf_dev_unpack_bayer (MSB-first, bits in {10, 12, 14, 16}), row r = frame row y0 - 2 + r, rows
+ * row_stride bytes apart.  Same output bits as rpf_dev_unpack_bayer followed by rpf_dev_develop, one pass less. */
+int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits,
+                           const rpf_raw_params* raw, void* d_out, int out_format, void* stream);
 /* the reference-equivalent back half: RGBA32F tile in -> out (wgsl main) */
 int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_format, void* stream);
 

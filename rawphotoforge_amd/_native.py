@@ -105,6 +105,7 @@ SYMBOLS = {
     "rpf_dev_rgb16be_to_rgba_f32": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "rpf_dev_demosaic": (C.c_int, [_vp, _vp, _P(RawParams), _P(Tile), _vp, _vp]),
     "rpf_dev_develop": (C.c_int, [_vp, _vp, _P(RawParams), _vp, C.c_int, _vp]),
+    "rpf_dev_develop_packed": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp]),
     "rpf_dev_apply": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "rpf_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }

@@ -744,6 +744,29 @@ int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* 
     return ok();
 }
 
+int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits,
+                           const rpf_raw_params* raw, void* d_out, int out_format, void* stream)
+{
+    int rc = need_device(e);
+    if (rc) return rc;
+    if (!d_packed || !raw || !d_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (bits != 10 && bits != 12 && bits != 14 && bits != 16)
+        return fail(RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT, "Unsupported read image format: packed samples must be 10, 12, 14 or 16 bits");
+    if (row_stride < ((size_t)e->geom.width * bits + 7) / 8 || row_stride > 0xffffffffu)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "row_stride shorter than a packed row");
+    HIP_TRY(hipSetDevice(e->proc->device));
+    if ((rc = sync_edit_state(e))) return rc;
+    if (e->dev.lens_strength != 0.0f)
+        return fail(RPF_ERR_INVALID_ARGUMENT,
+                    "lens distortion resamples the whole frame: unpack + demosaic first, then rpf_dev_apply on the full frame");
+    if (e->flavour != RPF_FLAVOUR_ACTIVE)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
+    e->dev.flags = 0;
+    HIP_TRY(launch_develop_packed(cfg_of(e->proc), d_packed, (uint32_t)row_stride, bits, make_raw_params(*raw), e->geom,
+                                  e->dev, d_out, out_format, (hipStream_t)stream));
+    return ok();
+}
+
 int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_format, void* stream)
 {
     int rc = need_device(e);

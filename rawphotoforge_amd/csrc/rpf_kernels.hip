@@ -194,6 +194,8 @@ struct StreamArgs {
     // Items [0, tail_start) are dealt whole.  The last, incomplete round — fewer items than waves — is cut into
     // single-pair sub-items: virtual item tail_start + t is pair (t % seg_pairs) of item tail_start + t / seg_pairs.
     uint32_t tail_start, nvirt;
+    // PACKED input (rpf_dev_develop_packed): cfa points at MSB-first bit-packed rows instead of a u16 plane
+    uint32_t bits, row_stride, row_bytes;  // sample width; bytes between rows; bytes of one row = ceil(W * bits / 8)
 };
 
 // One CFA row of a strip as the wavefront sees it: v = this lane's sample; p1 / p2 = the W+E sums at
@@ -213,7 +215,9 @@ __device__ __forceinline__ RowTaps row_taps(float v, float h, bool need_p2)
     return t;
 }
 
-template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // one global_load_dword at any byte address
+
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool PACKED = false>
 __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -286,26 +290,43 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
             int gy = reflect101(y0 + rbase + lane, H);
             int br = gy - (y0 - 2);
             br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);  // rows past a ragged band: unused
-            rowoff = (uint32_t)br * (uint32_t)W;
+            rowoff = (uint32_t)br * (PACKED ? a.row_stride : (uint32_t)W);  // bytes (packed) or elements
         }
-        auto row_ptr = [&](int j) -> const uint16_t* {  // j = window row of the item, wave-uniform
-            return a.cfa + __builtin_amdgcn_readlane(rowoff, j);
+        // PACKED: the integer unpack of rpf_dev_unpack_bayer folded into the row loads.  A lane's column fixes the
+        // byte address and the shift of its sample inside a 32-bit big-endian window once per item; the window is
+        // pulled back at the end of a row so that it never leaves the row (it still holds the whole sample).
+        uint32_t cbyte_g = 0, cshift_g = 0, cbyte_h = 0, cshift_h = 0;
+        const uint32_t smask = PACKED ? (1u << a.bits) - 1u : 0xffffu;
+        if (PACKED) {
+            auto col_addr = [&](int x, uint32_t& byte, uint32_t& shift) {
+                const uint32_t bit = (uint32_t)x * a.bits;
+                uint32_t b = bit >> 3;
+                const uint32_t last = a.row_bytes - 4u;
+                b = b > last ? last : b;
+                byte = b;
+                shift = 32u - a.bits - (bit - 8u * b);
+            };
+            col_addr(gx, cbyte_g, cshift_g);
+            col_addr(hx, cbyte_h, cshift_h);
+        }
+        auto sample = [&](int j, bool halo) -> uint32_t {  // j = window row of the item, wave-uniform
+            const uint32_t ro = __builtin_amdgcn_readlane(rowoff, j);
+            if (PACKED) {
+                const uint8_t* p = reinterpret_cast<const uint8_t*>(a.cfa) + ro + (halo ? cbyte_h : cbyte_g);
+                const uint32_t w = __builtin_bswap32(*reinterpret_cast<const u32_unaligned*>(p));
+                return (w >> (halo ? cshift_h : cshift_g)) & smask;
+            }
+            return (a.cfa + ro)[halo ? hx : gx];
         };
         auto normE = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkE, 0.0f), rngE) * sclE; };
         auto normO = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkO, 0.0f), rngO) * sclO; };
 
         // window position i <-> band row 2*pair - 2 + i
-        const uint16_t* q0 = row_ptr(0);
-        const uint16_t* q1 = row_ptr(1);
-        const uint16_t* q2 = row_ptr(2);
-        const uint16_t* q3 = row_ptr(3);
-        const uint16_t* q4 = row_ptr(4);
-        const uint16_t* q5 = row_ptr(5);
-        const float v0 = normE(q0[gx]);
-        RowTaps t1 = row_taps(normO(q1[gx]), normO(q1[hx]), false);
-        RowTaps t2 = row_taps(normE(q2[gx]), normE(q2[hx]), true);
-        RowTaps t3 = row_taps(normO(q3[gx]), normO(q3[hx]), true);
-        uint32_t n4 = q4[gx], n4h = q4[hx], n5 = q5[gx], n5h = q5[hx];
+        const float v0 = normE(sample(0, false));
+        RowTaps t1 = row_taps(normO(sample(1, false)), normO(sample(1, true)), false);
+        RowTaps t2 = row_taps(normE(sample(2, false)), normE(sample(2, true)), true);
+        RowTaps t3 = row_taps(normO(sample(3, false)), normO(sample(3, true)), true);
+        uint32_t n4 = sample(4, false), n4h = sample(4, true), n5 = sample(5, false), n5h = sample(5, true);
         float w0 = v0;
 
         const bool col_live = xl < W;
@@ -313,9 +334,8 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
             const RowTaps t4 = row_taps(normE(n4), normE(n4h), true);
             const RowTaps t5 = row_taps(normO(n5), normO(n5h), true);
             if (p + 1 < npairs) {  // prefetch the next step's two rows
-                const uint16_t* qa = row_ptr(2 * p + 6);
-                const uint16_t* qb = row_ptr(2 * p + 7);
-                n4 = qa[gx]; n4h = qa[hx]; n5 = qb[gx]; n5h = qb[hx];
+                n4 = sample(2 * p + 6, false); n4h = sample(2 * p + 6, true);
+                n5 = sample(2 * p + 7, false); n5h = sample(2 * p + 7, true);
             }
             // neighbourhood sums: top pixel = window position 2, bottom = 3
             const float c[2] = {t2.v, t3.v};
@@ -627,20 +647,26 @@ static hipError_t check_edit(const DeviceEdit& ed)
     return hipSuccess;
 }
 
-template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+struct PackedRows {  // bit-packed input of the fused kernel (bits == 0: d_cfa is a u16 plane)
+    uint32_t bits, row_stride;
+};
+
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool PACKED = false>
 static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                              const DeviceEdit* ed, void* d_out, hipStream_t s, uint32_t seg_pairs = 0,
-                             uint32_t blocks_per_cu = 0)
+                             uint32_t blocks_per_cu = 0, PackedRows pk = PackedRows{0, 0})
 {
     StreamArgs a;
     memset(&a, 0, sizeof(a));
     a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
+    a.bits = pk.bits; a.row_stride = pk.row_stride;
+    a.row_bytes = (uint32_t)(((uint64_t)g.width * pk.bits + 7) / 8);
     if (ed) a.ed = *ed;
     const uint32_t total_pairs = (g.rows + 1) / 2;
     a.strips = (g.width + STRIP_W - 1) / STRIP_W;
     constexpr uint32_t WPB = NT / 64;
     const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
-    auto kernel = k_stream<NT, MODE, LDS_LUT, OUTFMT>;
+    auto kernel = k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     // persistent workgroups for the fused kernel (LDS tables staged once per workgroup), as many as are resident: it
@@ -729,6 +755,42 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
                    : run_stream<256, MODE_DEVELOP_1, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+}
+
+template <int OUTFMT>
+static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_packed, PackedRows pk, const RawParamsDev& raw,
+                                     const TileGeom& g, const DeviceEdit& ed, void* d_out, hipStream_t s)
+{
+    const uint16_t* in = reinterpret_cast<const uint16_t*>(d_packed);
+    const bool lut = needs_lds_lut(ed);
+    if (ed.num_masks == 1)
+        return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
+                   : run_stream<256, MODE_DEVELOP_1, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+    return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
+               : run_stream<256, MODE_DEVELOP, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+}
+
+// d_packed: (rows + 4) packed rows, row r = frame row y0 - 2 + r, rows row_stride bytes apart (the band-buffer
+// layout of launch_develop in packed form)
+hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, uint32_t row_stride, uint32_t bits,
+                                 const RawParamsDev& raw, const TileGeom& g, const DeviceEdit& ed, void* d_out,
+                                 int out_format, hipStream_t s)
+{
+    hipError_t e = check_geom(g, true);
+    if (e == hipSuccess) e = check_edit(ed);
+    if (e != hipSuccess) return e;
+    if (!d_packed || !d_out) return hipErrorInvalidValue;
+    if (bits != 10 && bits != 12 && bits != 14 && bits != 16) return hipErrorInvalidValue;
+    if (row_stride < ((uint64_t)g.width * bits + 7) / 8) return hipErrorInvalidValue;
+    if ((uint64_t)row_stride * (g.rows + 4) > 0xffffffffull) return hipErrorInvalidValue;  // 32-bit row offsets
+    if (ed.lens_strength != 0.0f || ed.flags != 0) return hipErrorInvalidValue;
+    const PackedRows pk{bits, row_stride};
+    switch (out_format) {
+    case OUT_RGBA_F32: return develop_packed_fmt<OUT_RGBA_F32>(cfg, d_packed, pk, raw, g, ed, d_out, s);
+    case OUT_RGB_F32: return develop_packed_fmt<OUT_RGB_F32>(cfg, d_packed, pk, raw, g, ed, d_out, s);
+    case OUT_RGB_U8: return develop_packed_fmt<OUT_RGB_U8>(cfg, d_packed, pk, raw, g, ed, d_out, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,

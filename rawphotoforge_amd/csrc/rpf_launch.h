@@ -40,6 +40,10 @@ hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const Ra
                            float* d_rgba, hipStream_t s);
 hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                           const DeviceEdit& ed, void* d_out, int out_format, hipStream_t s);
+// the same with the integer unpack folded in: d_packed holds (rows + 4) MSB-first bit-packed rows (10/12/14/16 bits)
+hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, uint32_t row_stride, uint32_t bits,
+                                 const RawParamsDev& raw, const TileGeom& g, const DeviceEdit& ed, void* d_out,
+                                 int out_format, hipStream_t s);
 // d_in: rows x width RGBA32F (whole frame when lens_strength != 0)
 hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom& g, const DeviceEdit& ed, void* d_out,
                         int out_format, hipStream_t s);

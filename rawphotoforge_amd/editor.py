@@ -362,6 +362,13 @@ class PhotoEditor:
         _check(N.lib().rpf_dev_develop(self._h, C.c_void_p(d_cfa_ptr), C.byref(rp), C.c_void_p(d_out_ptr),
                                        out_format, C.c_void_p(stream)))
 
+    def dev_develop_packed(self, d_packed_ptr: int, row_stride: int, bits: int, raw: RawParams, d_out_ptr: int,
+                           out_format: int = N.OUT_RGBA_F32, stream: int = 0) -> None:
+        """Fused unpack + develop: the band's (rows + 4) rows bit-packed (MSB-first 10/12/14/16-bit)."""
+        rp = raw if isinstance(raw, N.RawParams) else raw.to_c()
+        _check(N.lib().rpf_dev_develop_packed(self._h, C.c_void_p(d_packed_ptr), row_stride, bits, C.byref(rp),
+                                              C.c_void_p(d_out_ptr), out_format, C.c_void_p(stream)))
+
     def dev_apply(self, d_in_ptr: int, d_out_ptr: int, out_format: int = N.OUT_RGBA_F32, stream: int = 0) -> None:
         _check(N.lib().rpf_dev_apply(self._h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr), out_format,
                                      C.c_void_p(stream)))

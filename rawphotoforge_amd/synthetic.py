@@ -82,3 +82,11 @@ def configure(ed, spec: dict, mask_name=None, main: bool = True) -> None:
             setter(curve=np.full(CURVE_RESOLUTION, c[1], np.int32), mask_name=mask_name)
         else:
             setter(curve=c[1], mask_name=mask_name)
+
+
+def pack_msb(cfa: np.ndarray, bits: int) -> np.ndarray:
+    """MSB-first bit-packing of a (rows, width) u16 plane, rows padded to whole bytes (synthetic packed-RAW input for
+    bench.py; the layout rpf_dev_unpack_bayer / rpf_dev_develop_packed read)."""
+    rows, w = cfa.shape
+    b = np.unpackbits(np.ascontiguousarray(cfa).astype(">u2").view(np.uint8).reshape(rows, w, 2), axis=2)[:, :, 16 - bits:]
+    return np.packbits(b.reshape(rows, w * bits), axis=1)

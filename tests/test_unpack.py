@@ -69,3 +69,60 @@ def test_gpu_unpack_rejects_bad_arguments(gpu):
         R.dev_unpack_bayer(gpu, 1, 64, 16, 1, 11, 1)       # unsupported bit depth
     with pytest.raises(R.InvalidArgument):
         R.dev_unpack_bayer(gpu, 1, 8, 16, 1, 12, 1)        # stride shorter than a row
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [10, 12, 14, 16])
+def test_gpu_fused_unpack_develop_bit_exact(gpu, bits):
+    """rpf_dev_develop_packed == unpack (oracle, integer) followed by the oracle's develop, on whole frames and on row
+    bands with halo rows, ragged widths, padded / odd row strides, all three output layouts."""
+    torch = pytest.importorskip("torch")
+    import rawphotoforge_amd as R
+    from tests import util
+    rng = np.random.default_rng(200 + bits)
+    white = (1 << bits) - 1
+    rp = O.RawParams(cfa_pattern=int(rng.integers(0, 4)), black=(white // 16,) * 4, white=white, wb=(1.9, 1.0, 1.0, 1.4))
+    s = torch.cuda.current_stream().cuda_stream
+    for (h, w, extra, pname) in ((40, 100, 0, "S"), (33, 37, 0, "D"), (9, 3, 0, "G"), (70, 200, 3, "S"), (24, 129, 5, "D")):
+        cfa = rng.integers(0, white + 1, (h, w), dtype=np.uint16)
+        p = {"D": util.params_D, "S": util.params_S, "G": util.params_G}[pname]()
+        want = O.develop(cfa, rp, [p])
+        stride = O.packed_row_stride(w, bits) + extra
+        # whole frame: halo rows exist in the buffer but are never read (reflect-101 at the frame edge)
+        pad = np.zeros((h + 4, w), np.uint16)
+        pad[2:-2] = cfa
+        d = torch.from_numpy(O.pack_bayer(pad, bits, stride)).cuda()
+        ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+        util.configure_editor(ed, p)
+        out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        ed.dev_develop_packed(d.data_ptr(), stride, bits, util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (h, w, extra, pname)
+        if h >= 24:   # a row band in the middle: its halo rows are real neighbours
+            y0, rows = 8, h - 14
+            band = torch.from_numpy(O.pack_bayer(cfa[y0 - 2:y0 + rows + 2], bits, stride)).cuda()
+            et = R.PhotoEditor.for_tile(gpu, w, h, y0, rows)
+            util.configure_editor(et, p)
+            o8 = torch.empty((rows, w, 3), dtype=torch.uint8, device="cuda")
+            et.dev_develop_packed(band.data_ptr(), stride, bits, util.to_raw(rp), o8.data_ptr(), R.OUT_RGB_U8, s)
+            torch.cuda.synchronize()
+            ref8 = (np.clip(want[y0:y0 + rows, :, :3], 0, 1) * np.float32(255.0)).astype(np.uint8)
+            assert np.array_equal(o8.cpu().numpy(), ref8)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_unpack_develop_rejects_bad_arguments(gpu):
+    torch = pytest.importorskip("torch")
+    import rawphotoforge_amd as R
+    from tests import util
+    ed = R.PhotoEditor.for_tile(gpu, 64, 16, 0, 16)
+    buf = torch.zeros(64 * 20 * 2, dtype=torch.uint8, device="cuda")
+    out = torch.empty((16, 64, 4), dtype=torch.float32, device="cuda")
+    raw = util.to_raw(util.raw_params())
+    with pytest.raises(R.PhotoEditorError):
+        ed.dev_develop_packed(buf.data_ptr(), 96, 11, raw, out.data_ptr())            # unsupported width
+    with pytest.raises(R.InvalidArgument):
+        ed.dev_develop_packed(buf.data_ptr(), 95, 12, raw, out.data_ptr())            # stride shorter than a row
+    ed.set_lens_distortion_correction(20)
+    with pytest.raises(R.InvalidArgument):
+        ed.dev_develop_packed(buf.data_ptr(), 96, 12, raw, out.data_ptr())            # needs the whole-frame pass
