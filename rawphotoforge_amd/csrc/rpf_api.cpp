@@ -78,6 +78,10 @@ struct rpf_processor {
     std::atomic<int> editors{0};
 };
 
+struct CurveStamps {
+    uint64_t v[4];
+};
+
 struct rpf_editor {
     rpf_processor* proc = nullptr;  // null: headless (state only)
     EditState state;
@@ -100,6 +104,7 @@ struct rpf_editor {
     uint32_t lut_capacity = 0;    // masks worth of LUT storage
     uint32_t mask_capacity = 0;   // user-mask planes allocated
     uint64_t uploaded_params = 0, uploaded_masks = 0;
+    std::vector<CurveStamps> uploaded_curves;  // per mask slot: EditParameters::curve_ver of what the device holds
     DeviceEdit dev{};
     hipStream_t stream = nullptr;
 
@@ -119,54 +124,80 @@ static int sync_edit_state(rpf_editor* e)
 static int sync_edit_state_impl(rpf_editor* e)
 {
     const uint32_t n = (uint32_t)e->state.masks.size();
-    if (e->uploaded_params != e->state.params_version) {
-        if (e->lut_capacity < n) {
-            if (e->d_bright) HIP_TRY(hipFree(e->d_bright));
-            if (e->d_hsl) HIP_TRY(hipFree(e->d_hsl));
-            e->d_bright = nullptr; e->d_hsl = nullptr;
-            HIP_TRY(hipMalloc((void**)&e->d_bright, (size_t)n * RPF_CURVE_RESOLUTION * sizeof(uint16_t)));
-            HIP_TRY(hipMalloc((void**)&e->d_hsl, (size_t)n * RPF_CURVE_RESOLUTION * sizeof(ushort4)));
-            e->lut_capacity = n;
-        }
-        std::vector<uint16_t> bright((size_t)n * RPF_CURVE_RESOLUTION);
-        std::vector<ushort4> hsl((size_t)n * RPF_CURVE_RESOLUTION);
-        for (uint32_t m = 0; m < n; ++m) {
-            const EditParameters& p = e->state.masks[m].params;
-            e->dev.mp[m] = make_mask_params(p);
-            for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) {
-                const size_t k = (size_t)m * RPF_CURVE_RESOLUTION + i;
-                bright[k] = (uint16_t)lut_clamp(p.curve[RPF_CURVE_BRIGHTNESS][i]);  // wgsl:188
-                hsl[k].x = (uint16_t)lut_clamp(p.curve[RPF_CURVE_HUE][i]);
-                hsl[k].y = (uint16_t)lut_clamp(p.curve[RPF_CURVE_SATURATION][i]);
-                hsl[k].z = (uint16_t)lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][i]);
-                hsl[k].w = 0;
-            }
-        }
-        // kernels launched earlier (on this editor's stream or a caller's) may still read the old tables
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(e->d_bright, bright.data(), bright.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e->d_hsl, hsl.data(), hsl.size() * sizeof(ushort4), hipMemcpyHostToDevice));
-        const rpf_gpu_edit_parameters g0 = convert_params(e->state.masks[0].params);
-        e->dev.vign_strength = (-g0.vignette / 100.0f) * 2.0f;     // wgsl:167 (main mask only, :276)
-        e->dev.lens_strength = -0.5f * (g0.lens_distortion / 100.0f);  // wgsl:110 (main mask only, :273)
-        e->dev.num_masks = n;
-        e->dev.bright = e->d_bright;
-        e->dev.hsl = e->d_hsl;
-        e->dev.tabs = e->proc->d_tabs;
-        e->dev.legacy = e->proc->d_legacy;
-        e->dev.hue_bounds = e->proc->d_hue_bounds;
-        e->uploaded_params = e->state.params_version;
+    if (e->uploaded_params == e->state.params_version && e->uploaded_masks == e->state.masks_version) return ok();
+    const bool masks_changed = e->uploaded_masks != e->state.masks_version;
+    bool synced = false;  // kernels launched earlier (on this editor's stream or a caller's) may still read the old tables
+    auto quiesce = [&]() -> int {
+        if (!synced) HIP_TRY(hipDeviceSynchronize());
+        synced = true;
+        return ok();
+    };
+    int rc;
+    if (e->lut_capacity < n) {
+        if ((rc = quiesce())) return rc;
+        if (e->d_bright) HIP_TRY(hipFree(e->d_bright));
+        if (e->d_hsl) HIP_TRY(hipFree(e->d_hsl));
+        e->d_bright = nullptr; e->d_hsl = nullptr;
+        HIP_TRY(hipMalloc((void**)&e->d_bright, (size_t)n * RPF_CURVE_RESOLUTION * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc((void**)&e->d_hsl, (size_t)n * RPF_CURVE_RESOLUTION * sizeof(ushort4)));
+        e->lut_capacity = n;
+        e->uploaded_curves.clear();
     }
-    if (e->uploaded_masks != e->state.masks_version) {
+    // a mask list that changed (add / remove / reset) may have moved every slot: upload all of them again
+    if (masks_changed) e->uploaded_curves.clear();
+    e->uploaded_curves.resize(n, CurveStamps{{~0ull, ~0ull, ~0ull, ~0ull}});
+    // only the curves a setter really changed go to the device (the reference re-uploads 1 MiB per mask per apply,
+    // gpu_image_processing.rs:257-307, and its callers re-send all four curves every frame, web/main.ts:809-826)
+    std::vector<uint16_t> bright;
+    std::vector<ushort4> hsl;
+    for (uint32_t m = 0; m < n; ++m) {
+        const EditParameters& p = e->state.masks[m].params;
+        e->dev.mp[m] = make_mask_params(p);
+        CurveStamps& up = e->uploaded_curves[m];
+        if (up.v[RPF_CURVE_BRIGHTNESS] != p.curve_ver[RPF_CURVE_BRIGHTNESS]) {
+            bright.resize(RPF_CURVE_RESOLUTION);
+            for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) bright[i] = (uint16_t)lut_clamp(p.curve[RPF_CURVE_BRIGHTNESS][i]);  // wgsl:188
+            if ((rc = quiesce())) return rc;
+            HIP_TRY(hipMemcpy(e->d_bright + (size_t)m * RPF_CURVE_RESOLUTION, bright.data(),
+                              bright.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            up.v[RPF_CURVE_BRIGHTNESS] = p.curve_ver[RPF_CURVE_BRIGHTNESS];
+        }
+        if (up.v[RPF_CURVE_HUE] != p.curve_ver[RPF_CURVE_HUE] || up.v[RPF_CURVE_SATURATION] != p.curve_ver[RPF_CURVE_SATURATION] ||
+            up.v[RPF_CURVE_LIGHTNESS] != p.curve_ver[RPF_CURVE_LIGHTNESS]) {
+            hsl.resize(RPF_CURVE_RESOLUTION);
+            for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) {
+                hsl[i].x = (uint16_t)lut_clamp(p.curve[RPF_CURVE_HUE][i]);
+                hsl[i].y = (uint16_t)lut_clamp(p.curve[RPF_CURVE_SATURATION][i]);
+                hsl[i].z = (uint16_t)lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][i]);
+                hsl[i].w = 0;
+            }
+            if ((rc = quiesce())) return rc;
+            HIP_TRY(hipMemcpy(e->d_hsl + (size_t)m * RPF_CURVE_RESOLUTION, hsl.data(), hsl.size() * sizeof(ushort4),
+                              hipMemcpyHostToDevice));
+            for (int c = RPF_CURVE_HUE; c <= RPF_CURVE_LIGHTNESS; ++c) up.v[c] = p.curve_ver[c];
+        }
+    }
+    const rpf_gpu_edit_parameters g0 = convert_params(e->state.masks[0].params);
+    e->dev.vign_strength = (-g0.vignette / 100.0f) * 2.0f;     // wgsl:167 (main mask only, :276)
+    e->dev.lens_strength = -0.5f * (g0.lens_distortion / 100.0f);  // wgsl:110 (main mask only, :273)
+    e->dev.num_masks = n;
+    e->dev.bright = e->d_bright;
+    e->dev.hsl = e->d_hsl;
+    e->dev.tabs = e->proc->d_tabs;
+    e->dev.legacy = e->proc->d_legacy;
+    e->dev.hue_bounds = e->proc->d_hue_bounds;
+    e->uploaded_params = e->state.params_version;
+    if (masks_changed) {
         const uint32_t planes = n - 1;
         const size_t plane = npix_of(e);
         if (planes > e->mask_capacity) {
+            if ((rc = quiesce())) return rc;
             if (e->d_masks) HIP_TRY(hipFree(e->d_masks));
             e->d_masks = nullptr;
             HIP_TRY(hipMalloc((void**)&e->d_masks, plane * planes));
             e->mask_capacity = planes;
         }
-        HIP_TRY(hipDeviceSynchronize());
+        if (planes && (rc = quiesce())) return rc;
         for (uint32_t m = 1; m < n; ++m)
             HIP_TRY(hipMemcpy(e->d_masks + (size_t)(m - 1) * plane, e->state.masks[m].binary.data(), plane,
                               hipMemcpyHostToDevice));

@@ -114,6 +114,35 @@ struct EditParameters {
     int32_t lens_distortion = 0;
     float mask_range = 0.0f;
     std::vector<int32_t> curve[4];  // brightness, hue, saturation, lightness
+    // Bookkeeping for callers that re-send every curve on every frame (web/main.ts:809-826): a stamp per curve
+    // (0 = the default; set_curve draws a new one from EditState::stamp only when the curve really changes), the
+    // control points that produced it, and what make_mask_params derives from it (identity / constant).
+    uint64_t curve_ver[4] = {0, 0, 0, 0};
+    std::vector<int32_t> cp_x[4], cp_y[4];
+    mutable uint64_t trait_ver[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    mutable bool trait_trivial[4] = {false, false, false, false};
+    mutable uint32_t trait_first[4] = {0, 0, 0, 0};
+
+    // identity (brightness, hue) / constant (saturation, lightness) after the fetch-time clamp, cached per stamp
+    bool curve_trivial(int which, uint32_t* first = nullptr) const
+    {
+        if (trait_ver[which] != curve_ver[which]) {
+            const std::vector<int32_t>& c = curve[which];
+            auto cl = [](int32_t v) { return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v)); };
+            const uint32_t v0 = cl(c[0]);
+            bool t = true;
+            if (which == RPF_CURVE_BRIGHTNESS || which == RPF_CURVE_HUE) {
+                for (int i = 0; i < RPF_CURVE_RESOLUTION && t; ++i) t = cl(c[i]) == (uint32_t)i;
+            } else {
+                for (int i = 0; i < RPF_CURVE_RESOLUTION && t; ++i) t = cl(c[i]) == v0;
+            }
+            trait_trivial[which] = t;
+            trait_first[which] = v0;
+            trait_ver[which] = curve_ver[which];
+        }
+        if (first) *first = trait_first[which];
+        return trait_trivial[which];
+    }
 
     EditParameters()
     {
@@ -171,19 +200,11 @@ inline MaskParams make_mask_params(const EditParameters& p)
     if (m.r_gain == 1.0f && m.g_gain == 1.0f && m.b_gain == 1.0f) f |= MF_UNITY_WB;
     if (m.exposure_mul == 1.0f) f |= MF_UNITY_EXPOSURE;
     if (g.shadow == 0.0f && g.highlight == 0.0f) f |= MF_NO_SHADOW_HIGHLIGHT;
-    bool ident_b = true, ident_h = true, const_s = true, const_l = true;
-    const uint32_t s0 = lut_clamp(p.curve[RPF_CURVE_SATURATION][0]);
-    const uint32_t l0 = lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][0]);
-    for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) {
-        ident_b = ident_b && lut_clamp(p.curve[RPF_CURVE_BRIGHTNESS][i]) == (uint32_t)i;
-        ident_h = ident_h && lut_clamp(p.curve[RPF_CURVE_HUE][i]) == (uint32_t)i;
-        const_s = const_s && lut_clamp(p.curve[RPF_CURVE_SATURATION][i]) == s0;
-        const_l = const_l && lut_clamp(p.curve[RPF_CURVE_LIGHTNESS][i]) == l0;
-    }
-    if (ident_b) f |= MF_BRIGHT_IDENTITY;
-    if (ident_h) f |= MF_HUE_IDENTITY;
-    if (const_s) { f |= MF_SAT_CONST; m.sat_gain = (float)s0 / 32767.5f; }    // wgsl:329
-    if (const_l) { f |= MF_LIGHT_CONST; m.light_gain = (float)l0 / 32767.5f; }  // wgsl:330
+    uint32_t s0 = 0, l0 = 0;
+    if (p.curve_trivial(RPF_CURVE_BRIGHTNESS)) f |= MF_BRIGHT_IDENTITY;
+    if (p.curve_trivial(RPF_CURVE_HUE)) f |= MF_HUE_IDENTITY;
+    if (p.curve_trivial(RPF_CURVE_SATURATION, &s0)) { f |= MF_SAT_CONST; m.sat_gain = (float)s0 / 32767.5f; }    // wgsl:329
+    if (p.curve_trivial(RPF_CURVE_LIGHTNESS, &l0)) { f |= MF_LIGHT_CONST; m.light_gain = (float)l0 / 32767.5f; }  // wgsl:330
     m.flags = f;
     return m;
 }
@@ -224,6 +245,7 @@ struct MaskState {
 struct EditState {
     uint32_t width = 0, height = 0;
     std::vector<MaskState> masks;
+    uint64_t stamp = 0;           // source of EditParameters::curve_ver
     uint64_t params_version = 1;  // bumped by every setter; device copies are refreshed lazily
     uint64_t masks_version = 1;
 
@@ -292,6 +314,15 @@ struct EditState {
         if (!curve && !xs)
             return Status::err(RPF_ERR_INTERP_MISSING_CURVE_OR_CONTROL_POINTS,
                                "Interpolation failed: You must provide either a full curve or control points.");
+        // Same control points as the ones this curve was built from: nothing to do (they passed every check then).
+        {
+            Status ignore;
+            const EditParameters* cur = find(mask_name, ignore);
+            if (cur && !curve && ys && n_x == n_y && n_x > 0 && cur->cp_x[which].size() == n_x &&
+                memcmp(cur->cp_x[which].data(), xs, n_x * sizeof(int32_t)) == 0 &&
+                memcmp(cur->cp_y[which].data(), ys, n_y * sizeof(int32_t)) == 0)
+                return Status::ok();
+        }
         std::vector<int32_t> final_curve;
         if (curve) {
             if (curve_len != RPF_CURVE_RESOLUTION)
@@ -321,7 +352,16 @@ struct EditState {
         Status st;
         EditParameters* a = find(mask_name, st);  // looked up last, as in lib.rs:341
         if (!a) return st;
+        if (curve) {
+            a->cp_x[which].clear();
+            a->cp_y[which].clear();
+            if (a->curve[which] == final_curve) return st;  // the same 65536 values again
+        } else {
+            a->cp_x[which].assign(xs, xs + n_x);
+            a->cp_y[which].assign(ys, ys + n_y);
+        }
         a->curve[which] = std::move(final_curve);
+        a->curve_ver[which] = ++stamp;
         ++params_version;
         return st;
     }

@@ -435,3 +435,59 @@ def test_editors_share_a_processor_and_interleave(gpu):
             ed.apply_adjustments()            # enqueue all three before reading any back
         for (ed, rgba), p in zip(eds, params):
             assert_parity(ed.rgba(), O.apply(rgba, [p]))
+
+
+def test_incremental_setter_traffic(gpu):
+    """Per-curve dirty tracking: after each small change (one curve, one slider, the same control points again, the
+    same full curve again, a mask added / removed, reset) the next apply must equal the oracle on the full state."""
+    h, w = 48, 96
+    img = _rgb_image(h, w, seed=21)
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    p = O.EditParameters()
+
+    def check(masks_params=None, masks=None):
+        ed.apply_adjustments()
+        assert_parity(ed.to_flat_vec_rgba(), O.apply(rgba, masks_params or [p], masks=masks))
+
+    check()
+    xs, ys = [0, 20000, 45000, 65535], [0, 26000, 40000, 65535]
+    ed.set_brightness_tone_curve(control_points_x=xs, control_points_y=ys)
+    p.brightness_tone_curve = O.curve_from_control_points(xs, ys)
+    check()
+    ed.set_brightness_tone_curve(control_points_x=xs, control_points_y=ys)      # same points again: no work, same result
+    check()
+    ed.set_oklch_hue_curve(control_points_x=[0, 30000, 65535], control_points_y=[2000, 28000, 65535])
+    p.hue_tone_curve = O.curve_from_control_points([0, 30000, 65535], [2000, 28000, 65535])
+    check()
+    ed.set_tone(0.4, 10, -20, 15, 0, 5)                                          # scalars only: no curve upload
+    p.exposure, p.contrast, p.shadow, p.highlight, p.black, p.white = 0.4, 10, -20, 15, 0, 5
+    check()
+    sat = np.full(65536, 40000, np.int32)
+    ed.set_oklch_saturation_curve(curve=sat)
+    p.saturation_tone_curve = sat
+    check()
+    ed.set_oklch_saturation_curve(curve=sat)                                     # same 65536 values again
+    check()
+    ys2 = [0, 20000, 45000, 60000]
+    ed.set_brightness_tone_curve(control_points_x=xs, control_points_y=ys2)     # same x, different y
+    p.brightness_tone_curve = O.curve_from_control_points(xs, ys2)
+    check()
+    with pytest.raises(R.NotStrictlyIncreasing):                                 # a failed call changes nothing
+        ed.set_brightness_tone_curve(control_points_x=[0, 5, 5], control_points_y=[0, 1, 2])
+    check()
+    rng = np.random.default_rng(3)
+    m = rng.random((h, w), dtype=np.float32)
+    ed.add_mask("sky", m)
+    q = util.params_G()
+    util.configure_editor(ed, q, mask_name="sky", main=False)
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(m, p.mask_range)])
+    check([p, q], masks)
+    ed.set_oklch_lightness_curve(control_points_x=[0, 65535], control_points_y=[30000, 36000], mask_name="sky")
+    q.lightness_tone_curve = O.curve_from_control_points([0, 65535], [30000, 36000])
+    check([p, q], masks)
+    ed.remove_mask("sky")
+    check()
+    ed.reset()
+    p = O.EditParameters()
+    check()
