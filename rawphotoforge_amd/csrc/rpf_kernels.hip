@@ -450,7 +450,7 @@ struct TexFetch {
     }
 };
 
-template <int NT, bool LDS_LUT, bool LENS, int OUTFMT>
+template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, bool SINGLE>
 __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -461,39 +461,60 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds};
     const int W = (int)a.g.width, H = (int)a.g.height;
-    const size_t npix = (size_t)a.g.rows * W;
-    const size_t stride = (size_t)gridDim.x * NT * 2;
-    for (size_t base = (size_t)blockIdx.x * NT * 2; base < npix; base += stride) {
+    const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
+    const uint32_t stride = gridDim.x * NT * 2;
+    const bool coords = LENS || a.ed.vign_strength != 0.0f;  // only these two stages look at the pixel position
+    // the pair's input is fetched one iteration ahead (the chain that follows is ~800 instructions long)
+    float4 nxt[2];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t p = base + (uint32_t)k * NT + tid;
+            nxt[k] = a.in[p < npix ? p : npix - 1];
+        }
+    };
+    uint32_t base = blockIdx.x * NT * 2;
+    if (!LENS && base < npix) fetch(base);
+    for (; base < npix; base += stride) {
         float r[2], g[2], b[2];
-        uint32_t active[2];
-        size_t pix[2];
+        uint32_t active[2] = {1u, 1u};
+        uint32_t pix[2];
         bool live[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const size_t p = base + (size_t)k * NT + tid;
+            const uint32_t p = base + (uint32_t)k * NT + tid;
             live[k] = p < npix;
             pix[k] = live[k] ? p : npix - 1;
-            const int ry = (int)(pix[k] / W), x = (int)(pix[k] - (size_t)ry * W);
-            const int gy = (int)a.g.y0 + ry;
-            if (LENS) {  // wgsl:123-163; a.in is the whole frame
-                lens_sample(TexFetch{a.in, W}, W, H, x, gy, a.ed.lens_strength, r[k], g[k], b[k]);
-            } else {
-                const float4 v = a.in[pix[k]];
-                r[k] = v.x; g[k] = v.y; b[k] = v.z;
-            }
-            if (a.ed.flags & EF_DECODE_INPUT) {  // Godot-legacy :281-283: the stored image is sRGB-encoded
-                const PowTable& D = a.ed.legacy->decode;
-                r[k] = srgb_to_linear1(r[k], D); g[k] = srgb_to_linear1(g[k], D); b[k] = srgb_to_linear1(b[k], D);
-            }
-            if (a.ed.vign_strength != 0.0f) {
-                const float gain = (a.ed.flags & EF_LEGACY_VIGNETTE)
-                                       ? vignette_gain_legacy(a.ed.vign_strength, x, gy, (float)W, (float)H)
-                                       : vignette_gain(a.ed.vign_strength, x, gy, (float)W, (float)H);
-                r[k] *= gain; g[k] *= gain; b[k] *= gain;
-            }
-            active[k] = a.ed.num_masks > 1 ? active_masks(a.ed, pix[k], npix) : 1u;
+            if (!LENS) { r[k] = nxt[k].x; g[k] = nxt[k].y; b[k] = nxt[k].z; }
         }
-        edit_chain<2>(r, g, b, active, a.ed.mp, a.ed.num_masks, luts, *T);
+        if (!LENS && base + stride < npix) fetch(base + stride);
+        const bool decode = (a.ed.flags & EF_DECODE_INPUT) != 0;  // Godot-legacy :281-283: the stored image is sRGB-encoded
+        auto decode_px = [&](int k) {
+            const PowTable& D = a.ed.legacy->decode;
+            r[k] = srgb_to_linear1(r[k], D); g[k] = srgb_to_linear1(g[k], D); b[k] = srgb_to_linear1(b[k], D);
+        };
+        if (coords) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ry = (int)(pix[k] / (uint32_t)W), x = (int)(pix[k] - (uint32_t)ry * (uint32_t)W);
+                const int gy = (int)a.g.y0 + ry;
+                if (LENS)  // wgsl:123-163; a.in is the whole frame
+                    lens_sample(TexFetch{a.in, W}, W, H, x, gy, a.ed.lens_strength, r[k], g[k], b[k]);
+                if (decode) decode_px(k);
+                if (a.ed.vign_strength != 0.0f) {
+                    const float gain = (a.ed.flags & EF_LEGACY_VIGNETTE)
+                                           ? vignette_gain_legacy(a.ed.vign_strength, x, gy, (float)W, (float)H)
+                                           : vignette_gain(a.ed.vign_strength, x, gy, (float)W, (float)H);
+                    r[k] *= gain; g[k] *= gain; b[k] *= gain;
+                }
+            }
+        } else if (decode) {
+            decode_px(0);
+            decode_px(1);
+        }
+        if (!SINGLE && a.ed.num_masks > 1)
+            for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
+        edit_chain<2>(r, g, b, active, a.ed.mp, SINGLE ? 1u : a.ed.num_masks, luts, *T);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (live[k]) store_px<OUTFMT>(a.out, pix[k], r[k], g[k], b[k]);
@@ -672,7 +693,16 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     // persistent workgroups for the fused kernel (LDS tables staged once per workgroup), as many as are resident: it
     // needs < 96 VGPRs, i.e. 5 waves per SIMD (variant 6: 4, for A/B); the 128-KiB curve in LDS limits that variant
     // to one 1024-thread workgroup per CU
-    const uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
+    uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
+    if (MODE != MODE_DEMOSAIC) {  // never more than are resident (a register count over 96 would halve the last round)
+        static int resident = 0;
+        if (resident == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NT, lds) != hipSuccess || nb < 1) nb = 1;
+            resident = nb;
+        }
+        if (per_cu > (uint32_t)resident) per_cu = (uint32_t)resident;
+    }
     const uint32_t cap_waves = (uint32_t)cfg.num_cus * per_cu * WPB;
     auto items_for = [&](uint32_t sp) { return a.strips * ((total_pairs + sp - 1) / sp); };
     // rows per item: 8 (demosaic: measured best; fused: enough waves for small frames); the fused kernel on a frame
@@ -810,16 +840,24 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
     }
 }
 
-template <bool LDS_LUT, bool LENS, int OUTFMT>
+template <bool LDS_LUT, bool LENS, int OUTFMT, bool SINGLE>
 static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
 {
     constexpr int NT = LDS_LUT ? 1024 : 256;
     const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0);
-    auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT>;
+    auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT, SINGLE>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     const size_t npix = (size_t)a.g.rows * a.g.width;
-    size_t grid = (size_t)cfg.num_cus * (LDS_LUT ? 1 : 8);
+    // persistent grid-stride workgroups: exactly as many as are resident (registers and the 28-KiB table copy in
+    // LDS decide; one more per CU would run as a second, mostly empty round)
+    static int resident = 0;
+    if (resident == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NT, lds) != hipSuccess || nb < 1) nb = 1;
+        resident = nb;
+    }
+    size_t grid = (size_t)cfg.num_cus * (size_t)resident;
     const size_t need = (npix + NT * 2 - 1) / (NT * 2);
     if (grid > need) grid = need;
     hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(NT), lds, s, a);
@@ -831,8 +869,12 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
 {
     const bool lut = needs_lds_lut(a.ed);
     const bool lens = a.ed.lens_strength != 0.0f;
-    if (lens) return lut ? run_apply<true, true, OUTFMT>(cfg, a, s) : run_apply<false, true, OUTFMT>(cfg, a, s);
-    return lut ? run_apply<true, false, OUTFMT>(cfg, a, s) : run_apply<false, false, OUTFMT>(cfg, a, s);
+    if (a.ed.num_masks == 1) {  // "main" only (the common case): per-mask loops and mask-plane reads compiled out
+        if (lens) return lut ? run_apply<true, true, OUTFMT, true>(cfg, a, s) : run_apply<false, true, OUTFMT, true>(cfg, a, s);
+        return lut ? run_apply<true, false, OUTFMT, true>(cfg, a, s) : run_apply<false, false, OUTFMT, true>(cfg, a, s);
+    }
+    if (lens) return lut ? run_apply<true, true, OUTFMT, false>(cfg, a, s) : run_apply<false, true, OUTFMT, false>(cfg, a, s);
+    return lut ? run_apply<true, false, OUTFMT, false>(cfg, a, s) : run_apply<false, false, OUTFMT, false>(cfg, a, s);
 }
 
 hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom& g, const DeviceEdit& ed, void* d_out,
