@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--out", default="rgba", choices=["rgba", "rgb", "u8"], help="output layout of the fused kernel")
+    ap.add_argument("--masks", type=int, default=1,
+                    help="N = 1 GPU: total number of masks (main + N-1 user masks of blobs covering ~half of the frame, "
+                         "each with edit set S); the headline figure is --masks 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos, then one launch per band")
     ap.add_argument("--cpu-rows", type=int, default=100)
@@ -77,10 +80,17 @@ def main():
     gen = syn.bayer_uniform if args.data == "U" else syn.bayer_natural
     cfa = gen(rows, W, seed=20260630 + rank)          # this rank's band (rank 0 at N=1: THE frame)
     band = tiles.make_band_buffer(cfa, device="cuda")   # (rows + 4, W) with halo rows
+    def configure(e):
+        syn.configure(e, spec)
+        for m in range(1, args.masks):   # user masks: smooth blobs thresholded at 0.5 (mask_range 0 -> v >= 0 keeps all,
+            yy, xx = np.mgrid[0:rows, 0:W]  # so the blobs are shifted below zero outside)
+            blob = np.sin(xx * (0.002 * m) + m) * np.cos(yy * (0.003 * m) - m)
+            e.add_mask(f"user{m}", np.where(blob > 0, 1.0, -1.0).astype(np.float32))
+            syn.configure(e, syn.PARAM_SETS["S"], mask_name=f"user{m}", main=False)
+
     ed = R.PhotoEditor.for_tile(gpu, W, frame_h, y0, rows)
-    syn.configure(ed, spec)
-    dev = tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, lambda e: syn.configure(e, spec), rank, world,
-                              overlap=not args.no_overlap)
+    configure(ed)
+    dev = tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, configure, rank, world, overlap=not args.no_overlap)
     out_fmt, out_bpp = {"rgba": (R.OUT_RGBA_F32, 16), "rgb": (R.OUT_RGB_F32, 12), "u8": (R.OUT_RGB_U8, 3)}[args.out]
     if args.workload != "develop" and args.out != "rgba":
         raise SystemExit("--out applies to the fused develop workload")
@@ -160,6 +170,7 @@ def main():
             "workload": (f"{W}x{H} RGGB u16 -> RGBA32F per GPU, fused {args.workload} "
                          f"(demosaic+WB+camera matrix+tone+curves+OKLCH+gamma), edit set {args.params}, "
                          f"data ({args.data}), frame {W}x{frame_h} in {world} row band(s)"
+                         + (f", {args.masks} masks" if args.masks > 1 else "")
                          + (", 2-row halo exchange per step" + ("" if args.no_overlap else
                             " hidden behind the interior rows (edge rows launched after it)") if world > 1 else "")),
             "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
