@@ -254,7 +254,20 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
 {
     const float inv65535 = (float)(1.0 / 65535.0);
     mask_rgb_stage<N>(mp[0], 0u, luts, r, g, b, nullptr);  // "main" is all ones (lib.rs:193-196)
+    // bits of the user masks that cover at least one pixel of this wavefront: a mask that covers none is skipped
+    // as a whole (wgsl:281 `continue` for every lane) — masks are regions, most wavefronts lie inside or outside
+    uint32_t any_active = 0;
+    for (int n = 0; n < N; ++n) any_active |= active[n];
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        uint32_t u = 0;
+        for (uint32_t m = 1; m < num_masks; ++m)
+            u |= (__builtin_amdgcn_ballot_w64((any_active >> m) & 1u) != 0ull) ? (1u << m) : 0u;
+        any_active = u | 1u;
+    }
+#endif
     for (uint32_t m = 1; m < num_masks; ++m) {
+        if (!((any_active >> m) & 1u)) continue;
         bool act[N];
         for (int n = 0; n < N; ++n) act[n] = (active[n] >> m) & 1u;
         mask_rgb_stage<N>(mp[m], m, luts, r, g, b, act);
@@ -298,7 +311,8 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         }
     };
     oklch_stage(0u, true);  // "main" is always active and replaces the hue by curve[k] / 65535
-    for (uint32_t m = 1; m < num_masks; ++m) oklch_stage(m, false);
+    for (uint32_t m = 1; m < num_masks; ++m)
+        if ((any_active >> m) & 1u) oklch_stage(m, false);
 
     // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336).  The hue reaching
     // here is always k/65535 for the integer k the last active mask fetched ("main" is always active).

@@ -13,26 +13,34 @@ void build_legacy_tables(LegacyTables& T);
 void build_hue_bounds(HueBound* B);
 }
 
-static rpf::MathTables g_tab;
-static bool g_ready = false;
+// function-local statics: initialised once, thread-safely (several loops below run under OpenMP)
 static const rpf::MathTables& tabs()
 {
-    if (!g_ready) { rpf::build_math_tables(g_tab); g_ready = true; }
-    return g_tab;
+    static const rpf::MathTables* t = [] {
+        rpf::MathTables* m = new rpf::MathTables;
+        rpf::build_math_tables(*m);
+        return m;
+    }();
+    return *t;
 }
 
 static const rpf::LegacyTables& legacy_tabs()
 {
-    static rpf::LegacyTables t;
-    static bool ready = false;
-    if (!ready) { rpf::build_legacy_tables(t); ready = true; }
-    return t;
+    static const rpf::LegacyTables* t = [] {
+        rpf::LegacyTables* m = new rpf::LegacyTables;
+        rpf::build_legacy_tables(*m);
+        return m;
+    }();
+    return *t;
 }
 
 static const rpf::HueBound* hue_bounds_tab()
 {
-    static rpf::HueBound* t = nullptr;
-    if (!t) { t = new rpf::HueBound[65536]; rpf::build_hue_bounds(t); }
+    static const rpf::HueBound* t = [] {
+        rpf::HueBound* b = new rpf::HueBound[65536];
+        rpf::build_hue_bounds(b);
+        return b;
+    }();
     return t;
 }
 
