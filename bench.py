@@ -40,7 +40,7 @@ def main():
                          "~50 launches (15 ms) to reach its steady clocks, and steady state is what a production "
                          "service sees (profiles/r01_experiments.md)")
     ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply", "unpack", "develop_packed"])
-    ap.add_argument("--params", default="D", choices=["D", "S", "G"])
+    ap.add_argument("--params", default="D", choices=["D", "S", "G", "V", "T"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--out", default="rgba", choices=["rgba", "rgb", "u8"], help="output layout of the fused kernel")

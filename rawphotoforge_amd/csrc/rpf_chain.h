@@ -91,13 +91,25 @@ RPF_HD void cam_to_linear(const float* m, float R, float G, float B, float& r, f
 // ---------------------------------------------------------------------------
 // wgsl:166-178 vignette — returns the gain; x, y are GLOBAL pixel coordinates
 // ---------------------------------------------------------------------------
+// The three steps separately, so that a kernel can hoist what is constant along a column / a row:
+//   vignette_axis2(i, n) = (((f32(i) / n) - 0.5) * 1.5)^2 for one axis, vignette_from_axes = the rest.
+RPF_HD float vignette_axis2(int i, float n)
+{
+    const float c = ((float)i / n - 0.5f) * 1.5f;
+    return c * c;
+}
+RPF_HD float vignette_from_axes(float vign_strength, float cx2, float cy2)
+{
+    const float dist = __builtin_sqrtf(cx2 + cy2);
+    // (dist - 0.25) / 0.75 by Markstein's sequence: equal to the IEEE quotient (every binary32 in [-0.25, 2] checked,
+    // tests/test_math_exhaustive.py)
+    const float t = div_by_const(dist - 0.25f, 0.75f, (float)(1.0 / 0.75));
+    const float falloff = pow_1p5(clampf(t, 0.0f, 1.0f));
+    return clampf(1.0f - (vign_strength * falloff), 0.0f, 4.0f);
+}
 RPF_HD float vignette_gain(float vign_strength, int x, int y, float w, float h)
 {
-    const float cx = ((float)x / w - 0.5f) * 1.5f;
-    const float cy = ((float)y / h - 0.5f) * 1.5f;
-    const float dist = __builtin_sqrtf(cx * cx + cy * cy);
-    const float falloff = pow_1p5(clampf((dist - 0.25f) / 0.75f, 0.0f, 1.0f));
-    return clampf(1.0f - (vign_strength * falloff), 0.0f, 4.0f);
+    return vignette_from_axes(vign_strength, vignette_axis2(x, w), vignette_axis2(y, h));
 }
 
 // The Godot-legacy flavour of the same shader (rust-godot-legacy/photo-editor/src/wgpu_shader.wgsl:173-186):

@@ -119,12 +119,15 @@ __device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T
 // The vertical pixel pair at one column: demosaic both sites (one is R/B, the other G), camera matrix,
 // then — MODE_DEVELOP — vignette and the edit chain on the pair in lockstep, and the two stores.
 // c/s1/e1/d/v2/h2 [0] = top pixel, [1] = bottom pixel.  cx = RGGB cell column of this lane, cy_top of the top row.
-template <int MODE, bool LDS_LUT, int OUTFMT>
+// VIGN: 0 = the launch has no vignette (code and registers compiled out), 1 = decided at run time from the pixel
+// position (generic), 2 = the caller hoisted the squared coordinates of the column and of the two rows.
+template <int MODE, bool LDS_LUT, int OUTFMT, int VIGN = 1>
 __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s1)[2], const float (&e1)[2],
                                             const float (&d)[2], const float (&v2)[2], const float (&h2)[2], int cx,
                                             int cy_top, const RawParamsDev& raw, const DeviceEdit& ed,
                                             const DevLuts<LDS_LUT>& luts, const MathTables& T, int gx, int ry_top,
-                                            const TileGeom& g, bool col_live, void* out, const float* cam)
+                                            const TileGeom& g, bool col_live, void* out, const float* cam,
+                                            float vcx2 = 0.0f, float vcy2_top = 0.0f, float vcy2_bot = 0.0f)
 {
     const bool topA = cx == cy_top;  // top pixel is the R/B site, bottom the G site
     const float cA = topA ? c[0] : c[1], s1A = topA ? s1[0] : s1[1], e1A = topA ? e1[0] : e1[1];
@@ -153,9 +156,11 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
         pix[k] = live[k] ? (size_t)(ry_top + k) * W + gx : 0;
     }
     if (MODE != MODE_DEMOSAIC) {
-        if (ed.vign_strength != 0.0f) {  // wgsl:166-178, global coordinates
+        if (VIGN == 2 || (VIGN == 1 && ed.vign_strength != 0.0f)) {  // wgsl:166-178, global coordinates
             for (int k = 0; k < 2; ++k) {
-                const float gain = vignette_gain(ed.vign_strength, gx, (int)g.y0 + ry_top + k, (float)W, (float)g.height);
+                const float gain = VIGN == 2
+                                       ? vignette_from_axes(ed.vign_strength, vcx2, k ? vcy2_bot : vcy2_top)
+                                       : vignette_gain(ed.vign_strength, gx, (int)g.y0 + ry_top + k, (float)W, (float)g.height);
                 r[k] *= gain; gg[k] *= gain; b[k] *= gain;
             }
         }
@@ -217,8 +222,10 @@ __device__ __forceinline__ RowTaps row_taps(float v, float h, bool need_p2)
 
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // one global_load_dword at any byte address
 
-template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool PACKED = false>
-__global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
+// 256-thread builds are launched five workgroups per CU: tell the register allocator (<= 96 VGPRs)
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool PACKED = false, bool VIGN = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 5 : 1)))
+void k_stream(const StreamArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     MathTables* T = reinterpret_cast<MathTables*>(smem);
@@ -318,6 +325,13 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
             }
             return (a.cfa + ro)[halo ? hx : gx];
         };
+        // Vignette (wgsl:166-178): the column's squared coordinate once per item; lane j holds the squared
+        // coordinate of the item's output row j (two IEEE divisions per lane per item instead of two per pixel)
+        float vcx2 = 0.0f, vcy2_lane = 0.0f;
+        if (VIGN) {
+            vcx2 = vignette_axis2(xl, (float)W);
+            vcy2_lane = vignette_axis2(y0 + 2 * pair0 + lane, (float)H);
+        }
         auto normE = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkE, 0.0f), rngE) * sclE; };
         auto normO = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkO, 0.0f), rngO) * sclO; };
 
@@ -344,8 +358,14 @@ __global__ __launch_bounds__(NT) void k_stream(const StreamArgs a)
             const float d[2] = {t1.p1 + t3.p1, t2.p1 + t4.p1};
             const float vv[2] = {w0 + t4.v, t1.v + t5.v};
             const float h2[2] = {t2.p2, t3.p2};
-            finish_pair<MODE, LDS_LUT, OUTFMT>(c, s1, e1, d, vv, h2, cx, bp, a.raw, a.ed, luts, *T, xl, 2 * (pair0 + p), a.g,
-                                               col_live, a.out, camv);
+            float vcy2_top = 0.0f, vcy2_bot = 0.0f;
+            if (VIGN) {  // wave-uniform; back into VGPRs (an SGPR operand halves the f32 rate)
+                vcy2_top = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p));
+                vcy2_bot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p + 1));
+            }
+            finish_pair<MODE, LDS_LUT, OUTFMT, VIGN ? 2 : 0>(c, s1, e1, d, vv, h2, cx, bp, a.raw, a.ed, luts, *T, xl,
+                                                             2 * (pair0 + p), a.g, col_live, a.out, camv, vcx2, vcy2_top,
+                                                             vcy2_bot);
             // slide the window down two rows
             w0 = t2.v; t1 = t3; t2 = t4; t3 = t5;
         }
@@ -687,7 +707,11 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     a.strips = (g.width + STRIP_W - 1) / STRIP_W;
     constexpr uint32_t WPB = NT / 64;
     const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
-    auto kernel = k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED>;
+    // two builds of every fused kernel: with the vignette stage (coordinates hoisted per column / per row) and
+    // without it (its code and registers compiled out: the plain kernel stays under 96 VGPRs)
+    const bool vign = MODE != MODE_DEMOSAIC && ed && ed->vign_strength != 0.0f;
+    auto kernel = vign ? k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED, MODE != MODE_DEMOSAIC>
+                       : k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED, false>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     // persistent workgroups for the fused kernel (LDS tables staged once per workgroup), as many as are resident: it
@@ -695,13 +719,13 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     // to one 1024-thread workgroup per CU
     uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
     if (MODE != MODE_DEMOSAIC) {  // never more than are resident (a register count over 96 would halve the last round)
-        static int resident = 0;
-        if (resident == 0) {
+        static int resident[2] = {0, 0};  // per build (without / with the vignette stage)
+        if (resident[vign] == 0) {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NT, lds) != hipSuccess || nb < 1) nb = 1;
-            resident = nb;
+            resident[vign] = nb;
         }
-        if (per_cu > (uint32_t)resident) per_cu = (uint32_t)resident;
+        if (per_cu > (uint32_t)resident[vign]) per_cu = (uint32_t)resident[vign];
     }
     const uint32_t cap_waves = (uint32_t)cfg.num_cus * per_cu * WPB;
     auto items_for = [&](uint32_t sp) { return a.strips * ((total_pairs + sp - 1) / sp); };

@@ -122,7 +122,7 @@ RPF_HD float div_by_const(float x, float d, float rd)
 // inputs are 0 or >= 7e-7 (M1 times channels that are multiples of 1/65535), and below 0.0031308 the gamma
 // stage takes its linear branch.
 template <int KIND, class TabT>
-RPF_HD float powc(float x, const TabT& T)
+RPF_HD double powc_d(float x, const TabT& T)  // the binary64 value before the single rounding
 {
     const uint32_t b = f2bits(x);
     const uint32_t eoff = (b >> 20) & 0x7f8u;  // biased exponent * 8: byte offset into E
@@ -142,7 +142,13 @@ RPF_HD float powc(float x, const TabT& T)
     p = __builtin_fma(t, p, K::c2);
     p = __builtin_fma(t, p, K::c1);
     p = __builtin_fma(t, p, 1.0);
-    return (float)((e2 * tj) * p);
+    return (e2 * tj) * p;
+}
+
+template <int KIND, class TabT>
+RPF_HD float powc(float x, const TabT& T)
+{
+    return (float)powc_d<KIND>(x, T);
 }
 
 // atan(q) = q + q^3 P(q^2), |q| <= tan(pi/8); rel. error 2^-52.7 (tools/gen_math_consts.py)
@@ -277,8 +283,9 @@ RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
     return k | zero_negx;
 }
 
-// pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171):
-// x*sqrt(x) in binary64 is within 2^-52 of the true value.
+// pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171): x * sqrt(x) in binary64 is within
+// 2^-52 of the true value, and exact whenever the result is exactly representable or a binary32 tie (x a perfect
+// square).  (The table scheme of powc was tried for it: same kernel time, and it needs a tie fix-up.)
 RPF_HD float pow_1p5(float x)
 {
     const double xd = (double)x;

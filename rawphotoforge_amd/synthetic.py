@@ -54,6 +54,9 @@ PARAM_SETS = {
               hue=("points", [0, 20000, 40000, 65535], [3000, 15000, 48000, 60000]),
               saturation=("points", [0, 30000, 65535], [20000, 45000, 30000]),
               lightness=("points", [0, 30000, 65535], [30000, 36000, 33000])),
+    # single-stage sets for cost attribution (bench.py --params V / T): the defaults plus one stage
+    "V": dict(vignette=-30),
+    "T": dict(exposure=0.5, contrast=20, shadow=30, highlight=-20, black=5, white=-5, wb_temperature=15, wb_tint=-10),
 }
 
 

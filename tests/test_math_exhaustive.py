@@ -85,10 +85,15 @@ def test_atan2_random_and_special():
         assert g == w and np.signbit(g) == np.signbit(w), (y, x, g, w)
 
 
-def test_pow_1p5_sampled():
+def test_pow_1p5_every_float_of_the_top_binades_and_samples():
+    # vignette falloff pow(t, 1.5), t in [0, 1] (wgsl:171)
+    n, bad = _sweep(4, 1.5, 2.0 ** -12, 1.0 + 2.0 ** -20)
+    assert n > 100_000_000 and bad == []
     tw, orc = util.twin(), O.lib()
     rng = np.random.default_rng(4)
-    for x in np.concatenate([rng.random(100_000).astype(np.float32), np.float32([0, 1, 1e-10, 0.25])]).tolist():
+    xs = np.concatenate([(rng.random(100_000) * 10.0 ** rng.uniform(-30, 0, 100_000)).astype(np.float32),
+                         np.float32([0, 1, 1e-10, 0.25, 1.2e-38, 1e-40])])
+    for x in xs.tolist():
         assert tw.twin_pow_1p5(x) == orc.orc_cr_powf(x, 1.5), x
 
 
@@ -203,3 +208,17 @@ def test_hue_index_special_arguments():
     # the documented exception: a true angle in (-3.5 * 2^-149, 0) — unreachable from the chain
     a, b = _hue_both(np.float32([-1e-45]), np.float32([1.0]))
     assert (int(a[0]), int(b[0])) == (65535, 0)
+
+
+def test_division_by_three_quarters_every_vignette_argument():
+    # (dist - 0.25) / 0.75 (wgsl:171): Markstein sequence vs IEEE division for every binary32 in [0, 2] and [-0.25, -0]
+    tw = util.twin()
+    d = np.float32(0.75)
+    for lo, hi in ((0, _bits(2.0)), (_bits(-0.0), _bits(-0.25) + 1)):
+        chunk = 1 << 25
+        for s in range(lo, hi, chunk):
+            n = min(chunk, hi - s)
+            got = np.empty(n, np.float32)
+            tw.twin_div_const_range(C.c_float(0.75), C.c_uint32(s), C.c_uint32(n), got.ctypes.data_as(C.c_void_p))
+            x = np.arange(s, s + n, dtype=np.uint32).view(np.float32)
+            assert np.array_equal(got.view(np.uint32), (x / d).view(np.uint32)), hex(s)

@@ -91,6 +91,13 @@ float twin_vignette_gain(int legacy, float strength, int x, int y, float w, floa
 }
 float twin_div_u16(uint32_t k, float d) { return rpf::div_u16_by(k, d, 1.0f / d); }
 float twin_div_two_pi(float x) { return rpf::div_by_const(x, RPF_K_TWO_PI_F, (float)(1.0 / (double)RPF_K_TWO_PI_F)); }
+void twin_div_const_range(float d, uint32_t bits_lo, uint32_t n, float* out)
+{
+    const float rd = (float)(1.0 / (double)d);
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i)
+        out[i] = rpf::div_by_const(rpf::bits2f(bits_lo + (uint32_t)i), d, rd);
+}
 void twin_div_two_pi_range(uint32_t bits_lo, uint32_t n, float* out)
 {
 #pragma omp parallel for schedule(static)
@@ -114,6 +121,7 @@ void twin_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
         out[i] = which == 0   ? rpf::powc<rpf::POW_CBRT>(x, T.cbrt)
                  : which == 1 ? rpf::powc<rpf::POW_GAMMA>(x, T.gamma)
                  : which == 2 ? rpf::powc<rpf::POW_DECODE>(x, L.decode)
+                 : which == 4 ? rpf::pow_1p5(x)
                               : rpf::pow_4(x);
     }
 }
