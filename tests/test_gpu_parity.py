@@ -34,7 +34,7 @@ def bayer_editor(gpu, cfa, rp):
 
 
 # ---- BASELINE config 2: demosaic only ---------------------------------------------------------
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
 @pytest.mark.parametrize("shape", [(64, 64), (67, 130), (19, 257), (3, 3), (8, 5), (301, 6)])
 def test_demosaic_bit_exact(gpu, shape, variant):
     gpu.set_kernel_variant(variant)
@@ -60,7 +60,7 @@ def test_demosaic_saturated_and_below_black(gpu):
 GOLD = np.load(os.path.join(util.GOLDEN, "chain_golden.npz"))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 10])   # every A/B variant of rpf_set_kernel_variant: same bits
 @pytest.mark.parametrize("pname", ["D", "S"])
 @pytest.mark.parametrize("tag", ["U", "N"])
 def test_develop_matches_committed_golden(gpu, tag, pname, variant):
