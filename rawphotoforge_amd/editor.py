@@ -326,20 +326,29 @@ class PhotoEditor:
     def sync(self) -> None:
         _check(N.lib().rpf_editor_sync(self._h))
 
-    def to_flat_vec_rgba(self) -> np.ndarray:
-        out = np.empty(self.width * self.height * 4, np.float32)
+    # `out`: an array of the right size and dtype to read into (a caller that reads frame after frame should reuse
+    # one: first-touch page faults of a fresh 384-MB buffer cost more than the transfer)
+    def _out(self, out, n, dtype):
+        if out is None:
+            return np.empty(n, dtype)
+        if out.dtype != dtype or out.size != n or not out.flags.c_contiguous:
+            raise InvalidArgument(f"out must be a C-contiguous {np.dtype(dtype).name} array of {n} elements")
+        return out
+
+    def to_flat_vec_rgba(self, out=None) -> np.ndarray:
+        out = self._out(out, self.width * self.height * 4, np.float32)
         _check(N.lib().rpf_get_rgba_f32(self._h, _ptr(out, C.c_float)))
         return out
 
-    def to_flat_vec_rgb(self) -> np.ndarray:
-        out = np.empty(self.width * self.height * 3, np.float32)
+    def to_flat_vec_rgb(self, out=None) -> np.ndarray:
+        out = self._out(out, self.width * self.height * 3, np.float32)
         _check(N.lib().rpf_get_rgb_f32(self._h, _ptr(out, C.c_float)))
         return out
 
-    def to_rgb_array3_u8(self) -> np.ndarray:
-        out = np.empty((self.height, self.width, 3), np.uint8)
+    def to_rgb_array3_u8(self, out=None) -> np.ndarray:
+        out = self._out(out, self.width * self.height * 3, np.uint8)
         _check(N.lib().rpf_get_rgb_u8(self._h, _ptr(out, C.c_uint8)))
-        return out
+        return out.reshape(self.height, self.width, 3)
 
     def rgba(self) -> np.ndarray:
         return self.to_flat_vec_rgba().reshape(self.height, self.width, 4)

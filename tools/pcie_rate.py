@@ -21,8 +21,20 @@ for rep in range(3):
     b = ed.to_flat_vec_rgb(); t4 = time.perf_counter()
     c = ed.to_rgb_array3_u8(); t5 = time.perf_counter()
     rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4))
+# the same with caller-owned, already touched output buffers (what a caller that processes many frames does)
+oa, ob, oc = np.zeros(W * H * 4, np.float32), np.zeros(W * H * 3, np.float32), np.zeros(W * H * 3, np.uint8)
+rows2 = []
+for rep in range(3):
+    t2 = time.perf_counter(); ed.to_flat_vec_rgba(oa); t3 = time.perf_counter()
+    ed.to_flat_vec_rgb(ob); t4 = time.perf_counter()
+    ed.to_rgb_array3_u8(oc); t5 = time.perf_counter()
+    rows2.append((t3 - t2, t4 - t3, t5 - t4))
+m2 = np.median(np.array(rows2), axis=0)
+print(f"into reused host buffers: get rgba f32 {m2[0]*1e3:.1f} ms ({384/m2[0]/1e3:.1f} GB/s) | get rgb f32 {m2[1]*1e3:.1f} ms | get rgb u8 {m2[2]*1e3:.1f} ms")
 m = np.median(np.array(rows), axis=0)
 mp = W * H / 1e6
 print(f"create(H2D 48MB) {m[0]*1e3:.1f} ms | apply {m[1]*1e3:.2f} ms | get rgba f32 {m[2]*1e3:.1f} ms | get rgb f32 {m[3]*1e3:.1f} ms | get rgb u8 {m[4]*1e3:.1f} ms")
 for name, t in (("rgba f32", m[0] + m[1] + m[2]), ("rgb f32", m[0] + m[1] + m[3]), ("rgb u8", m[0] + m[1] + m[4])):
-    print(f"end to end, host in -> host out ({name}): {t*1e3:.1f} ms = {mp/t:.0f} MP/s")
+    print(f"end to end, host in -> freshly allocated host out ({name}): {t*1e3:.1f} ms = {mp/t:.0f} MP/s")
+for name, t in (("rgba f32", m[0] + m[1] + m2[0]), ("rgb f32", m[0] + m[1] + m2[1]), ("rgb u8", m[0] + m[1] + m2[2])):
+    print(f"end to end, host in -> reused host out ({name}): {t*1e3:.1f} ms = {mp/t:.0f} MP/s")
