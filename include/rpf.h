@@ -244,7 +244,8 @@ int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_edito
  * fused develop: 1 = LDS-tile front end (first design), 2 = 512-thread workgroups, 3 = pixel pair sequentially,
  * 6 = 4 instead of 5 waves per SIMD, 7 = the general multi-mask kernel also when only "main" exists,
  * 8 = no splitting of the last, incomplete round of work items, 9 = 8-row instead of 32-/16-row work items,
- * 10 = brightness curve gathered from L2 instead of staged in LDS;
+ * 10 = brightness curve gathered from L2 instead of staged in LDS, 11 = cos / sin of the hue evaluated (sincos_hue)
+ * also when the hue curve is the identity (instead of read with the hue-index table entry);
  * demosaic: 1 = LDS-tile front end, 3 = ordinary (not nontemporal) stores, 4 = 16-row items.  Same output bits. */
 int rpf_set_kernel_variant(rpf_processor* p, int variant);
 

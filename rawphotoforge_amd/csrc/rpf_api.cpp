@@ -16,7 +16,7 @@
 namespace rpf {
 void build_math_tables(MathTables& T);
 void build_legacy_tables(LegacyTables& T);
-void build_hue_bounds(HueBound* B);
+void build_hue_bounds(HueBound* B, HueBoundCs* Cs, const MathTables& T);
 }
 
 using namespace rpf;
@@ -75,6 +75,7 @@ struct rpf_processor {
     MathTables* d_tabs = nullptr;
     LegacyTables* d_legacy = nullptr;  // Godot-legacy flavour only
     HueBound* d_hue_bounds = nullptr;  // 65536 entries, 1 MiB
+    HueBoundCs* d_hue_cs = nullptr;    // 65536 entries, 2 MiB (HUE_DIRECT launches)
     std::atomic<int> editors{0};
 };
 
@@ -186,6 +187,7 @@ static int sync_edit_state_impl(rpf_editor* e)
     e->dev.tabs = e->proc->d_tabs;
     e->dev.legacy = e->proc->d_legacy;
     e->dev.hue_bounds = e->proc->d_hue_bounds;
+    e->dev.hue_cs = e->proc->d_hue_cs;
     e->uploaded_params = e->state.params_version;
     if (masks_changed) {
         const uint32_t planes = n - 1;
@@ -295,16 +297,20 @@ int rpf_processor_create(int device, rpf_processor** out)
     std::unique_ptr<LegacyTables> legacy(new LegacyTables);
     build_legacy_tables(*legacy);
     std::vector<HueBound> bounds(RPF_CURVE_RESOLUTION);
-    build_hue_bounds(bounds.data());
+    std::vector<HueBoundCs> hcs(RPF_CURVE_RESOLUTION);
+    build_hue_bounds(bounds.data(), hcs.data(), *tabs);
     e = hipMalloc((void**)&p->d_legacy, sizeof(LegacyTables));
     if (e == hipSuccess) e = hipMemcpy(p->d_legacy, legacy.get(), sizeof(LegacyTables), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_hue_bounds, bounds.size() * sizeof(HueBound));
     if (e == hipSuccess)
         e = hipMemcpy(p->d_hue_bounds, bounds.data(), bounds.size() * sizeof(HueBound), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_hue_cs, hcs.size() * sizeof(HueBoundCs));
+    if (e == hipSuccess) e = hipMemcpy(p->d_hue_cs, hcs.data(), hcs.size() * sizeof(HueBoundCs), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(p->d_tabs);
         if (p->d_legacy) (void)hipFree(p->d_legacy);
         if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
+        if (p->d_hue_cs) (void)hipFree(p->d_hue_cs);
         return hip_fail(e, "tables", RPF_ERR_GPU_INITIALIZATION);
     }
     *out = p.release();
@@ -318,6 +324,7 @@ void rpf_processor_destroy(rpf_processor* p)
         if (p->d_tabs) (void)hipFree(p->d_tabs);
         if (p->d_legacy) (void)hipFree(p->d_legacy);
         if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
+        if (p->d_hue_cs) (void)hipFree(p->d_hue_cs);
     }
     delete p;
 }

@@ -260,7 +260,10 @@ RPF_HD void mask_rgb_stage(const MaskParams& P, uint32_t m, const Luts& luts, fl
 // wgsl main :279-336 on N pixels in lockstep (same operations per pixel, interleaved so that
 // constants are materialised once and the binary64 chains of different pixels overlap).
 // In place: r,g,b hold linear RGB on entry and the clamped display RGB on exit.
-template <int N, class Luts, class Tabs>
+// HUE_DIRECT (the caller's promise: num_masks == 1 and "main"'s hue curve is the identity): the index the hue
+// becomes IS the new hue, and cos / sin of its angle come with the boundary-table entry (hue_index_cs) instead of
+// being evaluated by sincos_hue.  A compile-time choice: as a run-time branch it splits the pair's gathers again.
+template <int N, bool HUE_DIRECT = false, class Luts, class Tabs>
 RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],
                        const MaskParams* mp, uint32_t num_masks, const Luts& luts, const Tabs& T)
 {
@@ -286,7 +289,7 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
     }
 
     // linear_srgb_to_oklch, wgsl:64-75.  The hue is only ever used as a curve index (hue_index, rpf_math.h).
-    float L[N], C[N], h[N];
+    float L[N], C[N], h[N], cs0[N], sn0[N];
     uint32_t hu0[N];
     for (int n = 0; n < N; ++n) {
         const float l = RPF_F(0.4122214708) * r[n] + RPF_F(0.5363325363) * g[n] + RPF_F(0.0514459929) * b[n];
@@ -301,7 +304,13 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
         const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;
         C[n] = __builtin_sqrtf(A * A + Bq * Bq);
-        hu0[n] = hue_index(Bq, A, luts.hue_bounds());  // u32(h * 65535), h = atan2(b, a) / (2 pi) wrapped, wgsl:72-73, 320
+        // u32(h * 65535), h = atan2(b, a) / (2 pi) wrapped (wgsl:72-73, 320)
+        if (HUE_DIRECT) {
+            hu0[n] = hue_index_cs(Bq, A, luts.hue_bounds_cs(), T.sc, cs0[n], sn0[n]);
+        } else {
+            hu0[n] = hue_index(Bq, A, luts.hue_bounds());
+            cs0[n] = sn0[n] = 0.0f;
+        }
     }
 
     // per-mask OKLCH curves, wgsl:312-331
@@ -329,8 +338,8 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
     // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336).  The hue reaching
     // here is always k/65535 for the integer k the last active mask fetched ("main" is always active).
     for (int n = 0; n < N; ++n) {
-        float cs, sn;
-        sincos_hue(hue_k[n], T.sc, cs, sn);
+        float cs = cs0[n], sn = sn0[n];
+        if (!HUE_DIRECT) sincos_hue(hue_k[n], T.sc, cs, sn);
         const float oa = C[n] * cs, ob = C[n] * sn;
         const float l_ = RPF_F(1.0) * L[n] + RPF_F(0.3963377774) * oa + RPF_F(0.2158037573) * ob;
         const float m_ = RPF_F(1.0) * L[n] + RPF_F(-0.1055613458) * oa + RPF_F(-0.0638541728) * ob;

@@ -30,7 +30,8 @@ namespace rpf {
 
 // _SEQ (A/B only): the pair one pixel after the other.  _1: only the "main" mask exists (the common case): the
 // per-mask loops and the mask-plane reads are compiled out, which also frees the scalar registers they pin.
-enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2, MODE_DEVELOP_1 = 3 };
+// _1H: _1 whose hue curve is the identity as well (edit_chain's HUE_DIRECT).
+enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2, MODE_DEVELOP_1 = 3, MODE_DEVELOP_1H = 4 };
 enum { OUT_RGBA_F32_PLAIN = 3 };  // internal (A/B only): RGBA32F with ordinary stores
 
 // ---------------------------------------------------------------------------
@@ -42,7 +43,9 @@ struct DevLuts {
     const uint16_t* g_bright;
     const ushort4* g_hsl;
     const HueBound* g_hue_bounds;
+    const HueBoundCs* g_hue_cs;
     __device__ __forceinline__ const HueBound* hue_bounds() const { return g_hue_bounds; }
+    __device__ __forceinline__ const HueBoundCs* hue_bounds_cs() const { return g_hue_cs; }
     __device__ __forceinline__ uint32_t brightness(uint32_t m, uint32_t i) const
     {
         if (LDS_LUT && m == 0) return lds_bright[i];
@@ -165,9 +168,11 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
             }
         }
         uint32_t active[2] = {1u, 1u};
-        if (MODE != MODE_DEVELOP_1 && ed.num_masks > 1)
+        if (MODE != MODE_DEVELOP_1 && MODE != MODE_DEVELOP_1H && ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(ed, pix[k], (size_t)rows * W);
-        if (MODE == MODE_DEVELOP_1) {
+        if (MODE == MODE_DEVELOP_1H) {
+            edit_chain<2, true>(r, gg, b, active, ed.mp, 1u, luts, T);
+        } else if (MODE == MODE_DEVELOP_1) {
             edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
         } else if (MODE == MODE_DEVELOP_SEQ) {
             for (int k = 0; k < 2; ++k) {
@@ -235,7 +240,7 @@ void k_stream(const StreamArgs a)
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
 
     const int lane = tid & 63;
     const int W = (int)a.g.width, H = (int)a.g.height;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
     const int lx = tid & (TILE_W - 1);
     const int ly = 2 * (tid / TILE_W);
     const int lane = tid & 63;
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
 
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         const int tx0 = (int)(t % a.tiles_x) * TILE_W;
@@ -470,7 +475,8 @@ struct TexFetch {
     }
 };
 
-template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, bool SINGLE>
+// SINGLE: 0 = any number of masks, 1 = only "main", 2 = only "main" with an identity hue curve (HUE_DIRECT)
+template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE>
 __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     const int tid = threadIdx.x;
     stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     __syncthreads();
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
     const uint32_t stride = gridDim.x * NT * 2;
@@ -534,7 +540,10 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         }
         if (!SINGLE && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
-        edit_chain<2>(r, g, b, active, a.ed.mp, SINGLE ? 1u : a.ed.num_masks, luts, *T);
+        if (SINGLE == 2)
+            edit_chain<2, true>(r, g, b, active, a.ed.mp, 1u, luts, *T);
+        else
+            edit_chain<2>(r, g, b, active, a.ed.mp, SINGLE ? 1u : a.ed.num_masks, luts, *T);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (live[k]) store_px<OUTFMT>(a.out, pix[k], r[k], g[k], b[k]);
@@ -683,7 +692,7 @@ static hipError_t check_geom(const TileGeom& g, bool bayer)
 
 static hipError_t check_edit(const DeviceEdit& ed)
 {
-    if (!ed.tabs || !ed.hue_bounds || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS) return hipErrorInvalidValue;
+    if (!ed.tabs || !ed.hue_bounds || !ed.hue_cs || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS) return hipErrorInvalidValue;
     if (ed.num_masks > 1 && !ed.mask_planes) return hipErrorInvalidValue;
     return hipSuccess;
 }
@@ -804,9 +813,13 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
                    : run_stream<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     if (OUTFMT == OUT_RGBA_F32 && !lut && cfg.variant == 3)  // A/B: the pixel pair one after the other
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
-    if (ed.num_masks == 1 && cfg.variant != 7)  // variant 7 (A/B): the general kernel on a single mask
+    if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
+        if ((ed.mp[0].flags & MF_HUE_IDENTITY) && cfg.variant != 11)  // variant 11 (A/B): sincos_hue also for an identity hue curve
+            return lut ? run_stream<1024, MODE_DEVELOP_1H, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
+                       : run_stream<256, MODE_DEVELOP_1H, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
         return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                    : run_stream<256, MODE_DEVELOP_1, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    }
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
 }
@@ -817,9 +830,13 @@ static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_pack
 {
     const uint16_t* in = reinterpret_cast<const uint16_t*>(d_packed);
     const bool lut = needs_lds_lut(ed);
-    if (ed.num_masks == 1)
+    if (ed.num_masks == 1) {
+        if (ed.mp[0].flags & MF_HUE_IDENTITY)
+            return lut ? run_stream<1024, MODE_DEVELOP_1H, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
+                       : run_stream<256, MODE_DEVELOP_1H, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
         return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                    : run_stream<256, MODE_DEVELOP_1, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+    }
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
 }
@@ -864,7 +881,7 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
     }
 }
 
-template <bool LDS_LUT, bool LENS, int OUTFMT, bool SINGLE>
+template <bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE>
 static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
 {
     constexpr int NT = LDS_LUT ? 1024 : 256;
@@ -894,11 +911,13 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
     const bool lut = needs_lds_lut(a.ed);
     const bool lens = a.ed.lens_strength != 0.0f;
     if (a.ed.num_masks == 1) {  // "main" only (the common case): per-mask loops and mask-plane reads compiled out
-        if (lens) return lut ? run_apply<true, true, OUTFMT, true>(cfg, a, s) : run_apply<false, true, OUTFMT, true>(cfg, a, s);
-        return lut ? run_apply<true, false, OUTFMT, true>(cfg, a, s) : run_apply<false, false, OUTFMT, true>(cfg, a, s);
+        // (HUE_DIRECT, SINGLE == 2, is not used here: with this kernel's 16-B/px input stream the 32-byte table read
+        // costs more than sincos_hue saves — D 0.234 -> 0.249 ms)
+        if (lens) return lut ? run_apply<true, true, OUTFMT, 1>(cfg, a, s) : run_apply<false, true, OUTFMT, 1>(cfg, a, s);
+        return lut ? run_apply<true, false, OUTFMT, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 1>(cfg, a, s);
     }
-    if (lens) return lut ? run_apply<true, true, OUTFMT, false>(cfg, a, s) : run_apply<false, true, OUTFMT, false>(cfg, a, s);
-    return lut ? run_apply<true, false, OUTFMT, false>(cfg, a, s) : run_apply<false, false, OUTFMT, false>(cfg, a, s);
+    if (lens) return lut ? run_apply<true, true, OUTFMT, 0>(cfg, a, s) : run_apply<false, true, OUTFMT, 0>(cfg, a, s);
+    return lut ? run_apply<true, false, OUTFMT, 0>(cfg, a, s) : run_apply<false, false, OUTFMT, 0>(cfg, a, s);
 }
 
 hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom& g, const DeviceEdit& ed, void* d_out,

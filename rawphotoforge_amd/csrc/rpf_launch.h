@@ -15,6 +15,7 @@ struct DeviceEdit {
     const ushort4* hsl;          // num_masks x 65536 {hue, sat, light, 0}
     const MathTables* tabs;
     const HueBound* hue_bounds;  // 65536 boundary directions of the hue index (rpf_math.h hue_index)
+    const HueBoundCs* hue_cs;    // the same boundaries with cos / sin of the hue angles attached (HUE_DIRECT launches)
     float vign_strength;         // (-vignette / 100) * 2, 0 = off       wgsl:167
     float lens_strength;         // -0.5 * (lens_distortion / 100), 0 = off   wgsl:110
     // Godot-legacy shader flavour (k_apply only): EF_* bits, and the c = 2.4 table when EF_DECODE_INPUT is set

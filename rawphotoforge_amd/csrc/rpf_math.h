@@ -239,10 +239,20 @@ RPF_HD void sincos_hue(uint32_t k, const TabT& S, float& cs, float& sn)
 // ~2^-75 (a rounded sum of three products of cube roots >= 2^-50) and |a| < 8, so it cannot occur.
 // ---------------------------------------------------------------------------
 struct HueBound {
+    double c, s;  // direction of the boundary at which the index first reaches j
+};
+// The table HUE_DIRECT launches read instead (one 32-byte gather; two tables with the same index, or one table for
+// everybody, both measured slower): the boundary plus cos, sin of the hue angle of index j (what sincos_hue(j)
+// returns) and of index j - 1 — with an identity hue curve the index IS the new hue (wgsl:324-328).
+struct HueBoundCs {
     double c, s;
+    float cs_k[2];
+    float cs_km1[2];
 };
 
-RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
+// `bd_out` / `passed_out`: the table entry that was read and the side of its boundary (for hue_index_cs)
+template <class Entry>
+RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out, bool& passed_out, uint32_t& zero_negx_out)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
     const float mx = ax > ay ? ax : ay;
@@ -274,13 +284,41 @@ RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
     v = x < 0.0f ? 32767.5f - v : v;   // pi - a
     v = y < 0.0f ? 65535.0f - v : v;   // 2 pi - a (the wrap of wgsl:73); y = -0 counts as +0, like atan2's -0 result
     const uint32_t j = (uint32_t)(v + 0.5f) & 0xffffu;
-    const HueBound bd = hb[j];
+    const Entry bd = hb[j];
     const double d = __builtin_fma((double)y, bd.c, -((double)x * bd.s));
-    const uint32_t k = (j - (d >= 0.0 ? 0u : 1u)) & 0xffffu;
+    const bool passed = d >= 0.0;
+    const uint32_t k = (j - (passed ? 0u : 1u)) & 0xffffu;
+    bd_out = bd;
+    passed_out = passed;
     // a = b = 0 arrives here as j = 0, d = +-0, k = 0, which is atan2(+-0, +0) = +-0 -> 0;
     // atan2(+-0, -0) = +-pi -> 32767 is OR-ed in (k is 0 in that case)
     const uint32_t zero_negx = (mx == 0.0f) ? ((f2bits(x) >> 31) * 32767u) : 0u;
+    zero_negx_out = zero_negx;
     return k | zero_negx;
+}
+
+RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
+{
+    HueBound bd;
+    bool passed;
+    uint32_t zn;
+    return hue_index_core(y, x, hb, bd, passed, zn);
+}
+
+// The index together with cos / sin of ITS hue angle (= sincos_hue(k)), read from the same table entry: for
+// launches whose hue curve is the identity the whole of sincos_hue (four LDS reads, eleven binary64 operations)
+// falls away.  The a = b = 0, a = -0 corner (k = 32767, not a neighbour of the entry read) takes the slow path.
+template <class TabT>
+RPF_HD uint32_t hue_index_cs(float y, float x, const HueBoundCs* hb, const TabT& S, float& cs, float& sn)
+{
+    HueBoundCs bd;
+    bool passed;
+    uint32_t zn;
+    const uint32_t k = hue_index_core(y, x, hb, bd, passed, zn);
+    cs = passed ? bd.cs_k[0] : bd.cs_km1[0];
+    sn = passed ? bd.cs_k[1] : bd.cs_km1[1];
+    if (__builtin_expect(zn != 0u, 0)) sincos_hue(k, S, cs, sn);
+    return k;
 }
 
 // pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171): x * sqrt(x) in binary64 is within

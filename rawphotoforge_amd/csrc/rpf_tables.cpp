@@ -44,12 +44,16 @@ static uint32_t hue_pipeline(float t)
     return (uint32_t)(h * 65535.0f);
 }
 
-void build_hue_bounds(HueBound* B)
+void build_hue_bounds(HueBound* B, HueBoundCs* Cs, const MathTables& T)
 {
     const uint32_t pi_bits = f2bits(RPF_K_PI_F);  // RN(pi): the largest magnitude atan2 returns
     const uint32_t k_pi = hue_pipeline(RPF_K_PI_F);
     B[0].c = 1.0;
     B[0].s = 0.0;
+    for (uint32_t j = 0; j < 65536; ++j) {  // what sincos_hue returns for the two indices an entry can decide between
+        sincos_hue(j, T.sc, Cs[j].cs_k[0], Cs[j].cs_k[1]);
+        sincos_hue((j - 1u) & 0xffffu, T.sc, Cs[j].cs_km1[0], Cs[j].cs_km1[1]);
+    }
     for (uint32_t j = 1; j < 65536; ++j) {
         long double theta;
         if (j <= k_pi) {  // first reached on the upper half circle: smallest t in [0, pi] with k(t) >= j
@@ -71,6 +75,10 @@ void build_hue_bounds(HueBound* B)
         }
         B[j].c = (double)cosl(theta);
         B[j].s = (double)sinl(theta);
+    }
+    for (uint32_t j = 0; j < 65536; ++j) {  // the 32-byte entries carry the same boundaries
+        Cs[j].c = B[j].c;
+        Cs[j].s = B[j].s;
     }
 }
 

@@ -10,7 +10,7 @@
 namespace rpf {
 void build_math_tables(MathTables& T);
 void build_legacy_tables(LegacyTables& T);
-void build_hue_bounds(HueBound* B);
+void build_hue_bounds(HueBound* B, HueBoundCs* Cs, const MathTables& T);
 }
 
 // function-local statics: initialised once, thread-safely (several loops below run under OpenMP)
@@ -34,15 +34,20 @@ static const rpf::LegacyTables& legacy_tabs()
     return *t;
 }
 
-static const rpf::HueBound* hue_bounds_tab()
+struct HueTabs {
+    rpf::HueBound* b;
+    rpf::HueBoundCs* c;
+};
+static const HueTabs& hue_tabs()
 {
-    static const rpf::HueBound* t = [] {
-        rpf::HueBound* b = new rpf::HueBound[65536];
-        rpf::build_hue_bounds(b);
-        return b;
+    static const HueTabs t = [] {
+        HueTabs h{new rpf::HueBound[65536], new rpf::HueBoundCs[65536]};
+        rpf::build_hue_bounds(h.b, h.c, tabs());
+        return h;
     }();
     return t;
 }
+static const rpf::HueBound* hue_bounds_tab() { return hue_tabs().b; }
 
 struct HostLuts {
     const int32_t* bright; const int32_t* hue; const int32_t* sat; const int32_t* light;
@@ -52,6 +57,7 @@ struct HostLuts {
         return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
     }
     const rpf::HueBound* hue_bounds() const { return hue_bounds_tab(); }
+    const rpf::HueBoundCs* hue_bounds_cs() const { return hue_tabs().c; }
     uint32_t brightness(uint32_t m, uint32_t i) const { return fetch(bright, m, i); }
     void hsl(uint32_t m, uint32_t i, const rpf::MaskParams&, uint32_t& nh, float& sg, float& lg) const
     {
