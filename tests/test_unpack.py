@@ -126,3 +126,35 @@ def test_gpu_fused_unpack_develop_rejects_bad_arguments(gpu):
     ed.set_lens_distortion_correction(20)
     with pytest.raises(R.InvalidArgument):
         ed.dev_develop_packed(buf.data_ptr(), 96, 12, raw, out.data_ptr())            # needs the whole-frame pass
+
+
+@pytest.mark.gpu
+def test_gpu_fused_unpack_develop_with_user_masks(gpu):
+    """Packed input through the general (multi-mask) kernel: two user masks with their own curves."""
+    torch = pytest.importorskip("torch")
+    import rawphotoforge_amd as R
+    from tests import util
+    rng = np.random.default_rng(77)
+    h, w, bits = 52, 150, 12
+    cfa = rng.integers(0, 1 << bits, (h, w), dtype=np.uint16)
+    rp = O.RawParams(cfa_pattern=O.CFA_GRBG, black=(200,) * 4, white=4095)
+    pm, p1, p2 = util.params_D(), util.params_S(), util.params_G()
+    m1, m2 = rng.random((h, w), dtype=np.float32), rng.random((h, w), dtype=np.float32)
+    ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+    ed.set_mask_range(0.5)
+    ed.add_mask("a", m1)
+    ed.add_mask("b", m2)
+    util.configure_editor(ed, pm)
+    util.configure_editor(ed, p1, mask_name="a", main=False)
+    util.configure_editor(ed, p2, mask_name="b", main=False)
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    stride = O.packed_row_stride(w, bits)
+    d = torch.from_numpy(O.pack_bayer(pad, bits, stride)).cuda()
+    out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    ed.dev_develop_packed(d.data_ptr(), stride, bits, util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(m1, 0.5), O.binarize_mask(m2, 0.5)])
+    want = O.develop(cfa, rp, [pm, p1, p2], masks=masks)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
