@@ -41,7 +41,43 @@ def atan_poly(deg=9, qmax=mp.mpf("0.4143")):
     return coeffs, err, worst
 
 
+def hue_candidate_poly(nterms=5):
+    """atan(q) * 65535 / (2 pi) ~ q * P(q^2) on [0, 1] for hue_index's candidate (numpy only): iteratively re-weighted
+    least squares towards the minimax fit; returns the binary32 coefficients and the max error in index units."""
+    import numpy as np
+    n = 2000
+    z = (np.cos(np.pi * (np.arange(n) + 0.5) / n) + 1) / 2
+    q = np.sqrt(z)
+    a = np.vander(z, nterms, increasing=True) * q[:, None]
+    w = np.ones(n)
+    for _ in range(60):
+        c, *_ = np.linalg.lstsq(a * w[:, None], np.arctan(q) * w, rcond=None)
+        e = a @ c - np.arctan(q)
+        w = w * (1 + 3 * np.abs(e) / np.abs(e).max())
+        w /= w.mean()
+    k = 65535 / (2 * np.pi)
+    c32 = [float(np.float32(v * k)) for v in c]
+    qq = np.linspace(0, 1, 200001)
+    err = qq * np.polyval(c32[::-1], qq * qq) - np.arctan(qq) * k
+    return c32, float(np.abs(err).max())
+
+
+def binomials(c_float32, kmax=5):
+    """binomial(c, k), k = 1..kmax, for c a binary32 value, as binary64 hex literals (PowCoef in rpf_math.h)."""
+    from fractions import Fraction
+    c = Fraction(float(c_float32))
+    b, out = Fraction(1), []
+    for k in range(1, kmax + 1):
+        b = b * (c - (k - 1)) / k
+        out.append(float(b).hex())
+    return out
+
+
 if __name__ == "__main__":
+    import numpy as _np
+    print("// hue_index candidate polynomial (index units), max error:", hue_candidate_poly())
+    for _name, _c in (("cbrt", _np.float32(1 / 3)), ("gamma", _np.float32(1 / 2.4)), ("decode", _np.float32(2.4))):
+        print(f"// PowCoef {_name}:", binomials(_c))
     for deg in (7, 8, 9):
         c, err, worst = atan_poly(deg)
         print(f"// atan P degree {deg}: chebyfit err {mp.nstr(err, 5)}, rel err of rounded poly {mp.nstr(worst, 5)}"
