@@ -162,7 +162,7 @@ def main():
     achieved = bpp * timed_rows * W / (kern_avg_ms * 1e-3) / 1e9   # GB/s, algorithmic bytes of ONE launch
 
     result = {
-        "metric": "megapixels/sec full RAW->sRGB chain, 6000x4000 Bayer; % HBM roofline",
+        "metric": "megapixels/sec full RAW\u2192sRGB chain, 6000\u00d74000 Bayer; % HBM roofline",   # BASELINE.json, verbatim
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
