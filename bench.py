@@ -224,13 +224,27 @@ def main():
         t1 = time.perf_counter()
         O.develop(cfa, raw, [p], y0=(H - args.cpu_rows) // 2 & ~1, rows=args.cpu_rows)
         c1 = time.perf_counter() - t1
+        # BASELINE configs[0]: python-legacy's CPU path (demosaic + WB + apply_gamma((2.222, 4.5)), editor.py:47-76) on a
+        # 512x512 frame, as restated in the oracle (pinned by tests/golden/legacy_helpers.npz), 1 thread / all cores
+        small = syn.bayer_uniform(512, 512, seed=20260630)
+        legacy = {}
+        for nthreads in (1, cores):
+            O.set_threads(nthreads)
+            O.legacy_develop(small, raw)
+            ts = []
+            for _ in range(9):
+                t1 = time.perf_counter()
+                O.legacy_develop(small, raw)
+                ts.append(time.perf_counter() - t1)
+            legacy[nthreads] = 512 * 512 / 1e6 / sorted(ts)[len(ts) // 2]
         O.set_threads(cores)
         result["cpu_baseline"] = {
             "value": round(W * H / 1e6 / ct, 3), "unit": "MP/s", "cores": cores, "kind": "port",
             "sample": (f"oracle/rpf_oracle.c (C restatement of the same chain, OpenMP, {cores} threads) on the whole "
                        f"{W}x{H} frame, median of {len(times)} passes ({sum(times):.1f} s wall, "
                        f"{sum(times) * cores:.0f} core-s); single thread on {args.cpu_rows} rows: "
-                       f"{args.cpu_rows * W / 1e6 / c1:.3f} MP/s"),
+                       f"{args.cpu_rows * W / 1e6 / c1:.3f} MP/s; python-legacy flavour (demosaic + WB + apply_gamma) "
+                       f"on 512x512: {legacy[1]:.1f} MP/s on 1 thread, {legacy[cores]:.1f} MP/s on {cores}"),
         }
     if rank == 0:
         print(json.dumps(result), flush=True)
