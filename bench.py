@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--masks", type=int, default=1,
                     help="N = 1 GPU: total number of masks (main + N-1 user masks of blobs covering ~half of the frame, "
                          "each with edit set S); the headline figure is --masks 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1.  nccl (= RCCL) is the measured configuration; gloo lets N ranks "
+                         "share ONE GPU (RCCL refuses that) to rehearse the N > 1 code path — its timings mean nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos, then one launch per band")
     ap.add_argument("--cpu-rows", type=int, default=100)
@@ -68,7 +71,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     gpu = R.GpuProcessor(local)
     gpu.set_kernel_variant(args.variant)
@@ -171,6 +177,8 @@ def main():
                          f"(demosaic+WB+camera matrix+tone+curves+OKLCH+gamma), edit set {args.params}, "
                          f"data ({args.data}), frame {W}x{frame_h} in {world} row band(s)"
                          + (f", {args.masks} masks" if args.masks > 1 else "")
+                         + (", REHEARSAL over gloo: ranks may share a GPU, timings are not a measurement"
+                            if world > 1 and args.backend != "nccl" else "")
                          + (", 2-row halo exchange per step" + ("" if args.no_overlap else
                             " hidden behind the interior rows (edge rows launched after it)") if world > 1 else "")),
             "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
