@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rehearsal of the N > 1 path on ONE GPU: start with
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/rehearse_ranks.py
-Every rank uses cuda:0 and the process group is gloo (RCCL refuses two ranks on one device; gloo moves CUDA tensors
+(N <= 5 on the shared boxes: the launcher counts towards their limit of 6 processes per GPU.)  Every rank uses cuda:0 and the process group is gloo (RCCL refuses two ranks on one device; gloo moves CUDA tensors
 through the host).  What is exercised is everything but the transport: the band split, tiles.BandDeveloper's
 three-launch schedule with a REAL asynchronous halo exchange between ranks, repeated steps on the same buffers, a new
 frame in the same buffers, and the result of every band against the oracle's whole-frame answer (bit for bit)."""
