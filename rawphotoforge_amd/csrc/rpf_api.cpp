@@ -155,7 +155,12 @@ static int sync_edit_state_impl(rpf_editor* e)
         const EditParameters& p = e->state.masks[m].params;
         e->dev.mp[m] = make_mask_params(p);
         CurveStamps& up = e->uploaded_curves[m];
-        if (up.v[RPF_CURVE_BRIGHTNESS] != p.curve_ver[RPF_CURVE_BRIGHTNESS]) {
+        // an identity brightness curve / trivial hue-saturation-lightness curves are never read by the kernels
+        // (make_mask_params flags them): nothing to pack or upload for them
+        const bool bright_read = !(e->dev.mp[m].flags & MF_BRIGHT_IDENTITY);
+        const bool hsl_read = (e->dev.mp[m].flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) !=
+                              (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
+        if (bright_read && up.v[RPF_CURVE_BRIGHTNESS] != p.curve_ver[RPF_CURVE_BRIGHTNESS]) {
             bright.resize(RPF_CURVE_RESOLUTION);
             for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) bright[i] = (uint16_t)lut_clamp(p.curve[RPF_CURVE_BRIGHTNESS][i]);  // wgsl:188
             if ((rc = quiesce())) return rc;
@@ -163,8 +168,9 @@ static int sync_edit_state_impl(rpf_editor* e)
                               bright.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             up.v[RPF_CURVE_BRIGHTNESS] = p.curve_ver[RPF_CURVE_BRIGHTNESS];
         }
-        if (up.v[RPF_CURVE_HUE] != p.curve_ver[RPF_CURVE_HUE] || up.v[RPF_CURVE_SATURATION] != p.curve_ver[RPF_CURVE_SATURATION] ||
-            up.v[RPF_CURVE_LIGHTNESS] != p.curve_ver[RPF_CURVE_LIGHTNESS]) {
+        if (hsl_read &&
+            (up.v[RPF_CURVE_HUE] != p.curve_ver[RPF_CURVE_HUE] || up.v[RPF_CURVE_SATURATION] != p.curve_ver[RPF_CURVE_SATURATION] ||
+             up.v[RPF_CURVE_LIGHTNESS] != p.curve_ver[RPF_CURVE_LIGHTNESS])) {
             hsl.resize(RPF_CURVE_RESOLUTION);
             for (int i = 0; i < RPF_CURVE_RESOLUTION; ++i) {
                 hsl[i].x = (uint16_t)lut_clamp(p.curve[RPF_CURVE_HUE][i]);
