@@ -491,3 +491,28 @@ def test_incremental_setter_traffic(gpu):
     ed.reset()
     p = O.EditParameters()
     check()
+
+
+def test_bench_prints_one_contract_line(gpu, capsys, monkeypatch):
+    """bench.py's output contract: ONE JSON line with the fields the driver and the judge read."""
+    import importlib
+    import json
+    import sys
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "6", "--warmup", "2", "--preheat", "4", "--cpu-seconds", "0.5"])
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    bench = importlib.import_module("bench")
+    bench.main()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    base = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")))
+    assert r["metric"] == base["metric"] and r["unit"] == "MP/s" and r["n_gpus"] == 1 and r["steps"] == 6 and r["warmup"] == 2
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["data"] == "synthetic"
+    assert r["value"] > 0 and abs(r["ms_per_step"] - 24.0 / r["value"] * 1e3) < 1e-2 * r["ms_per_step"]
+    assert "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "MP/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
