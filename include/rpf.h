@@ -212,12 +212,15 @@ typedef struct rpf_tile {
     uint32_t y0, rows;
 } rpf_tile;
 
-/* Packed RAW -> u16 CFA plane (integer, bit-exact).  MSB-first bit stream: sample i of a row occupies bits
- * [i*bits, (i+1)*bits) counted from the most significant bit of byte 0; rows start every row_stride bytes.
+/* Packed RAW -> u16 CFA plane (integer, bit-exact).  order RPF_PACK_MSB_FIRST: sample i of a row occupies bits
+ * [i*bits, (i+1)*bits) counted from the most significant bit of byte 0 (a big-endian bit stream);
+ * RPF_PACK_LSB_FIRST: the same bit positions counted from the least significant bit of byte 0, least significant
+ * sample bit first (the row read as one little-endian integer).  Rows start every row_stride bytes.
  * bits in {10, 12, 14, 16}.  d_cfa_out has pitch `width` (write it at row 2 of a band buffer).  In the reference
  * this step is inside rawler / LibRaw (rust-godot-legacy/photo-editor/src/image.rs:516-523). */
+enum { RPF_PACK_MSB_FIRST = 0, RPF_PACK_LSB_FIRST = 1 };
 int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows,
-                         uint32_t bits, uint16_t* d_cfa_out, void* stream);
+                         uint32_t bits, uint32_t order, uint16_t* d_cfa_out, void* stream);
 /* npix big-endian 16-bit RGB triplets (2-byte aligned) -> RGBA32F, v / 65535, alpha 1 (image.ts:172-189) */
 int rpf_dev_rgb16be_to_rgba_f32(rpf_processor* p, const uint8_t* d_rgb16be, size_t npix, float* d_rgba_out,
                                 void* stream);
@@ -230,9 +233,9 @@ int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_para
 int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* raw, void* d_out, int out_format,
                     void* stream);
 /* The same with the integer unpack folded into the kernel's row loads: d_packed holds the band's (rows + 4) rows in the
- * packed layout of rpf_dev_unpack_bayer (MSB-first, bits in {10, 12, 14, 16}), row r = frame row y0 - 2 + r, rows
+ * packed layout of rpf_dev_unpack_bayer (either bit order, bits in {10, 12, 14, 16}), row r = frame row y0 - 2 + r, rows
  * row_stride bytes apart.  Same output bits as rpf_dev_unpack_bayer followed by rpf_dev_develop, one pass less. */
-int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits,
+int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits, uint32_t order,
                            const rpf_raw_params* raw, void* d_out, int out_format, void* stream);
 /* the reference-equivalent back half: RGBA32F tile in -> out (wgsl main) */
 int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_format, void* stream);

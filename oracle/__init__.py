@@ -292,24 +292,27 @@ def packed_row_stride(width: int, bits: int, align: int = 4) -> int:
     return (n + align - 1) // align * align
 
 
-def pack_bayer(cfa, bits: int, row_stride=None) -> np.ndarray:
-    """MSB-first bit-packing of a (rows, width) u16 plane (test helper; inverse of unpack_bayer)."""
+PACK_MSB_FIRST, PACK_LSB_FIRST = 0, 1
+
+
+def pack_bayer(cfa, bits: int, row_stride=None, order=PACK_MSB_FIRST) -> np.ndarray:
+    """Bit-packing of a (rows, width) u16 plane (test helper; inverse of unpack_bayer)."""
     a = np.ascontiguousarray(cfa, np.uint16)
     rows, w = a.shape
     stride = row_stride or packed_row_stride(w, bits)
     out = np.zeros((rows, stride), np.uint8)
-    lib().orc_pack_bayer(_p(a, C.c_uint16), C.c_uint32(w), C.c_uint32(rows), C.c_uint32(bits), C.c_size_t(stride),
-                         _p(out, C.c_uint8))
+    fn = lib().orc_pack_bayer_lsb if order == PACK_LSB_FIRST else lib().orc_pack_bayer
+    fn(_p(a, C.c_uint16), C.c_uint32(w), C.c_uint32(rows), C.c_uint32(bits), C.c_size_t(stride), _p(out, C.c_uint8))
     return out
 
 
-def unpack_bayer(packed, width: int, bits: int) -> np.ndarray:
+def unpack_bayer(packed, width: int, bits: int, order=PACK_MSB_FIRST) -> np.ndarray:
     """This build's packed-RAW unpack definition (orc_unpack_bayer)."""
     p = np.ascontiguousarray(packed, np.uint8)
     rows, stride = p.shape
     out = np.empty((rows, width), np.uint16)
-    lib().orc_unpack_bayer(_p(p, C.c_uint8), C.c_size_t(stride), C.c_uint32(width), C.c_uint32(rows), C.c_uint32(bits),
-                           _p(out, C.c_uint16))
+    fn = lib().orc_unpack_bayer_lsb if order == PACK_LSB_FIRST else lib().orc_unpack_bayer
+    fn(_p(p, C.c_uint8), C.c_size_t(stride), C.c_uint32(width), C.c_uint32(rows), C.c_uint32(bits), _p(out, C.c_uint16))
     return out
 
 

@@ -34,6 +34,7 @@ ERR_TOO_MANY_MASKS = 33
 OUT_RGBA_F32, OUT_RGB_F32, OUT_RGB_U8 = 0, 1, 2
 CFA_RGGB, CFA_BGGR, CFA_GRBG, CFA_GBRG = 0, 1, 2, 3
 FLAVOUR_ACTIVE, FLAVOUR_GODOT_LEGACY = 0, 1
+PACK_MSB_FIRST, PACK_LSB_FIRST = 0, 1
 CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
 
 
@@ -101,11 +102,11 @@ SYMBOLS = {
     "rpf_editor_get_gpu_params": (C.c_int, [_vp, _cs, _P(GpuEditParameters)]),
     "rpf_editor_get_curve": (C.c_int, [_vp, C.c_int, _cs, _i32p]),
     "rpf_pchip_interpolate_i32": (C.c_int, [_i32p, _sz, _i32p, _sz, _i32p, _sz, _i32p, _i32p]),
-    "rpf_dev_unpack_bayer": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "rpf_dev_unpack_bayer": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "rpf_dev_rgb16be_to_rgba_f32": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "rpf_dev_demosaic": (C.c_int, [_vp, _vp, _P(RawParams), _P(Tile), _vp, _vp]),
     "rpf_dev_develop": (C.c_int, [_vp, _vp, _P(RawParams), _vp, C.c_int, _vp]),
-    "rpf_dev_develop_packed": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp]),
+    "rpf_dev_develop_packed": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp]),
     "rpf_dev_apply": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "rpf_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }

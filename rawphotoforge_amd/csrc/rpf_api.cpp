@@ -748,14 +748,15 @@ int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_para
 }
 
 int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows,
-                         uint32_t bits, uint16_t* d_cfa_out, void* stream)
+                         uint32_t bits, uint32_t order, uint16_t* d_cfa_out, void* stream)
 {
     if (!p || !d_packed || !d_cfa_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (order > RPF_PACK_LSB_FIRST) return fail(RPF_ERR_INVALID_ARGUMENT, "unknown bit order");
     if (bits != 10 && bits != 12 && bits != 14 && bits != 16)
         return fail(RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT, "Unsupported read image format: packed samples must be 10, 12, 14 or 16 bits");
     if (row_stride < ((size_t)width * bits + 7) / 8) return fail(RPF_ERR_INVALID_ARGUMENT, "row_stride shorter than a packed row");
     HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(launch_unpack(d_packed, row_stride, width, rows, bits, d_cfa_out, (hipStream_t)stream));
+    HIP_TRY(launch_unpack(d_packed, row_stride, width, rows, bits, order, d_cfa_out, (hipStream_t)stream));
     return ok();
 }
 
@@ -788,11 +789,12 @@ int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* 
     return ok();
 }
 
-int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits,
+int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits, uint32_t order,
                            const rpf_raw_params* raw, void* d_out, int out_format, void* stream)
 {
     int rc = need_device(e);
     if (rc) return rc;
+    if (order > RPF_PACK_LSB_FIRST) return fail(RPF_ERR_INVALID_ARGUMENT, "unknown bit order");
     if (!d_packed || !raw || !d_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
     if (bits != 10 && bits != 12 && bits != 14 && bits != 16)
         return fail(RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT, "Unsupported read image format: packed samples must be 10, 12, 14 or 16 bits");
@@ -806,7 +808,7 @@ int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_st
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
     e->dev.flags = 0;
-    HIP_TRY(launch_develop_packed(cfg_of(e->proc), d_packed, (uint32_t)row_stride, bits, make_raw_params(*raw), e->geom,
+    HIP_TRY(launch_develop_packed(cfg_of(e->proc), d_packed, (uint32_t)row_stride, bits, order, make_raw_params(*raw), e->geom,
                                   e->dev, d_out, out_format, (hipStream_t)stream));
     return ok();
 }

@@ -206,6 +206,7 @@ struct StreamArgs {
     uint32_t tail_start, nvirt;
     // PACKED input (rpf_dev_develop_packed): cfa points at MSB-first bit-packed rows instead of a u16 plane
     uint32_t bits, row_stride, row_bytes;  // sample width; bytes between rows; bytes of one row = ceil(W * bits / 8)
+    uint32_t lsb;                          // 0 = MSB-first bit stream, 1 = LSB-first (little-endian)
 };
 
 // One CFA row of a strip as the wavefront sees it: v = this lane's sample; p1 / p2 = the W+E sums at
@@ -316,7 +317,7 @@ void k_stream(const StreamArgs a)
                 const uint32_t last = a.row_bytes - 4u;
                 b = b > last ? last : b;
                 byte = b;
-                shift = 32u - a.bits - (bit - 8u * b);
+                shift = a.lsb ? bit - 8u * b : 32u - a.bits - (bit - 8u * b);
             };
             col_addr(gx, cbyte_g, cshift_g);
             col_addr(hx, cbyte_h, cshift_h);
@@ -325,7 +326,8 @@ void k_stream(const StreamArgs a)
             const uint32_t ro = __builtin_amdgcn_readlane(rowoff, j);
             if (PACKED) {
                 const uint8_t* p = reinterpret_cast<const uint8_t*>(a.cfa) + ro + (halo ? cbyte_h : cbyte_g);
-                const uint32_t w = __builtin_bswap32(*reinterpret_cast<const u32_unaligned*>(p));
+                const uint32_t raw32 = *reinterpret_cast<const u32_unaligned*>(p);
+                const uint32_t w = a.lsb ? raw32 : __builtin_bswap32(raw32);
                 return (w >> (halo ? cshift_h : cshift_g)) & smask;
             }
             return (a.cfa + ro)[halo ? hx : gx];
@@ -616,11 +618,12 @@ __global__ __launch_bounds__(256) void k_resize(const float4* src, uint32_t sw, 
 }
 
 // ---------------------------------------------------------------------------
-// k_unpack — packed RAW (10/12/14/16-bit, MSB-first bit stream) -> u16 CFA plane.  Integer, bit-exact.
+// k_unpack — packed RAW (10/12/14/16-bit; MSB-first bit stream, or LSB-first = little-endian) -> u16 CFA plane.
+// Integer, bit-exact.
 // One thread = 16 samples = 2*BITS bytes read as BITS/2 dwords and two 16-B stores; a group that is
 // ragged (row end) or unaligned goes sample by sample.
 // ---------------------------------------------------------------------------
-template <int BITS>
+template <int BITS, bool LSB>
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, size_t row_stride, uint32_t width, uint32_t rows,
                                                 uint16_t* out, uint32_t groups_per_row)
 {
@@ -637,15 +640,19 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, size_t ro
             uint32_t w[NW + 1];
             const uint32_t* src = reinterpret_cast<const uint32_t*>(row + (size_t)g * (2 * BITS));
 #pragma unroll
-            for (int k = 0; k < NW; ++k) w[k] = __builtin_bswap32(src[k]);  // big-endian words of the bit stream
+            for (int k = 0; k < NW; ++k) w[k] = LSB ? src[k] : __builtin_bswap32(src[k]);  // words of the bit stream
             w[NW] = 0;
             uint32_t v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                constexpr int dummy = 0; (void)dummy;
                 const int o = j * BITS, i = o >> 5, sh = o & 31;
-                const uint64_t two = ((uint64_t)w[i] << 32) | w[i + 1];
-                v[j] = (uint32_t)(two >> (64 - sh - BITS)) & MASK;
+                if (LSB) {
+                    const uint64_t two = ((uint64_t)w[i + 1] << 32) | w[i];
+                    v[j] = (uint32_t)(two >> sh) & MASK;
+                } else {
+                    const uint64_t two = ((uint64_t)w[i] << 32) | w[i + 1];
+                    v[j] = (uint32_t)(two >> (64 - sh - BITS)) & MASK;
+                }
             }
             uint4 a, b;
             a.x = v[0] | (v[1] << 16); a.y = v[2] | (v[3] << 16); a.z = v[4] | (v[5] << 16); a.w = v[6] | (v[7] << 16);
@@ -658,9 +665,15 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, size_t ro
                 const size_t by = (size_t)(bit >> 3);
                 const uint32_t sh = (uint32_t)(bit & 7);
                 // BITS + 7 <= 23 bits span at most 3 bytes (4 for 16-bit samples never: sh is 0 there)
-                uint32_t acc = ((uint32_t)row[by] << 16) | ((uint32_t)row[by + 1] << 8);
-                if (sh + BITS > 16) acc |= row[by + 2];
-                orow[x] = (uint16_t)((acc >> (24 - sh - BITS)) & MASK);
+                if (LSB) {
+                    uint32_t acc = (uint32_t)row[by] | ((uint32_t)row[by + 1] << 8);
+                    if (sh + BITS > 16) acc |= (uint32_t)row[by + 2] << 16;
+                    orow[x] = (uint16_t)((acc >> sh) & MASK);
+                } else {
+                    uint32_t acc = ((uint32_t)row[by] << 16) | ((uint32_t)row[by + 1] << 8);
+                    if (sh + BITS > 16) acc |= row[by + 2];
+                    orow[x] = (uint16_t)((acc >> (24 - sh - BITS)) & MASK);
+                }
             }
         }
     }
@@ -698,18 +711,18 @@ static hipError_t check_edit(const DeviceEdit& ed)
 }
 
 struct PackedRows {  // bit-packed input of the fused kernel (bits == 0: d_cfa is a u16 plane)
-    uint32_t bits, row_stride;
+    uint32_t bits, row_stride, lsb;
 };
 
 template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool PACKED = false>
 static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                              const DeviceEdit* ed, void* d_out, hipStream_t s, uint32_t seg_pairs = 0,
-                             uint32_t blocks_per_cu = 0, PackedRows pk = PackedRows{0, 0})
+                             uint32_t blocks_per_cu = 0, PackedRows pk = PackedRows{0, 0, 0})
 {
     StreamArgs a;
     memset(&a, 0, sizeof(a));
     a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
-    a.bits = pk.bits; a.row_stride = pk.row_stride;
+    a.bits = pk.bits; a.row_stride = pk.row_stride; a.lsb = pk.lsb;
     a.row_bytes = (uint32_t)(((uint64_t)g.width * pk.bits + 7) / 8);
     if (ed) a.ed = *ed;
     const uint32_t total_pairs = (g.rows + 1) / 2;
@@ -844,7 +857,7 @@ static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_pack
 // d_packed: (rows + 4) packed rows, row r = frame row y0 - 2 + r, rows row_stride bytes apart (the band-buffer
 // layout of launch_develop in packed form)
 hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, uint32_t row_stride, uint32_t bits,
-                                 const RawParamsDev& raw, const TileGeom& g, const DeviceEdit& ed, void* d_out,
+                                 uint32_t order, const RawParamsDev& raw, const TileGeom& g, const DeviceEdit& ed, void* d_out,
                                  int out_format, hipStream_t s)
 {
     hipError_t e = check_geom(g, true);
@@ -855,7 +868,8 @@ hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, 
     if (row_stride < ((uint64_t)g.width * bits + 7) / 8) return hipErrorInvalidValue;
     if ((uint64_t)row_stride * (g.rows + 4) > 0xffffffffull) return hipErrorInvalidValue;  // 32-bit row offsets
     if (ed.lens_strength != 0.0f || ed.flags != 0) return hipErrorInvalidValue;
-    const PackedRows pk{bits, row_stride};
+    if (order > 1u) return hipErrorInvalidValue;
+    const PackedRows pk{bits, row_stride, order};
     switch (out_format) {
     case OUT_RGBA_F32: return develop_packed_fmt<OUT_RGBA_F32>(cfg, d_packed, pk, raw, g, ed, d_out, s);
     case OUT_RGB_F32: return develop_packed_fmt<OUT_RGB_F32>(cfg, d_packed, pk, raw, g, ed, d_out, s);
@@ -943,19 +957,31 @@ hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom&
 }
 
 hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows, uint32_t bits,
-                         uint16_t* d_out, hipStream_t s)
+                         uint32_t order, uint16_t* d_out, hipStream_t s)
 {
     if (width == 0 || rows == 0) return hipSuccess;
     if (!d_packed || !d_out) return hipErrorInvalidValue;
-    if (row_stride < ((size_t)width * bits + 7) / 8) return hipErrorInvalidValue;
+    if (row_stride < ((size_t)width * bits + 7) / 8 || order > 1u) return hipErrorInvalidValue;
     const uint32_t gpr = (width + 15) / 16;
     const size_t total = (size_t)gpr * rows;
     const uint32_t grid = (uint32_t)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     switch (bits) {
-    case 10: hipLaunchKernelGGL(k_unpack<10>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
-    case 12: hipLaunchKernelGGL(k_unpack<12>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
-    case 14: hipLaunchKernelGGL(k_unpack<14>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
-    case 16: hipLaunchKernelGGL(k_unpack<16>, dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr); break;
+    case 10:
+        if (order) hipLaunchKernelGGL((k_unpack<10, true>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        else hipLaunchKernelGGL((k_unpack<10, false>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        break;
+    case 12:
+        if (order) hipLaunchKernelGGL((k_unpack<12, true>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        else hipLaunchKernelGGL((k_unpack<12, false>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        break;
+    case 14:
+        if (order) hipLaunchKernelGGL((k_unpack<14, true>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        else hipLaunchKernelGGL((k_unpack<14, false>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        break;
+    case 16:
+        if (order) hipLaunchKernelGGL((k_unpack<16, true>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        else hipLaunchKernelGGL((k_unpack<16, false>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -372,10 +372,10 @@ class PhotoEditor:
                                        out_format, C.c_void_p(stream)))
 
     def dev_develop_packed(self, d_packed_ptr: int, row_stride: int, bits: int, raw: RawParams, d_out_ptr: int,
-                           out_format: int = N.OUT_RGBA_F32, stream: int = 0) -> None:
-        """Fused unpack + develop: the band's (rows + 4) rows bit-packed (MSB-first 10/12/14/16-bit)."""
+                           out_format: int = N.OUT_RGBA_F32, stream: int = 0, order: int = N.PACK_MSB_FIRST) -> None:
+        """Fused unpack + develop: the band's (rows + 4) rows bit-packed (10/12/14/16-bit, MSB- or LSB-first)."""
         rp = raw if isinstance(raw, N.RawParams) else raw.to_c()
-        _check(N.lib().rpf_dev_develop_packed(self._h, C.c_void_p(d_packed_ptr), row_stride, bits, C.byref(rp),
+        _check(N.lib().rpf_dev_develop_packed(self._h, C.c_void_p(d_packed_ptr), row_stride, bits, order, C.byref(rp),
                                               C.c_void_p(d_out_ptr), out_format, C.c_void_p(stream)))
 
     def dev_apply(self, d_in_ptr: int, d_out_ptr: int, out_format: int = N.OUT_RGBA_F32, stream: int = 0) -> None:
@@ -417,7 +417,7 @@ def dev_rgb16be_to_rgba_f32(processor: GpuProcessor, d_samples_ptr: int, npix: i
 
 
 def dev_unpack_bayer(processor: GpuProcessor, d_packed_ptr: int, row_stride: int, width: int, rows: int, bits: int,
-                     d_cfa_ptr: int, stream: int = 0) -> None:
-    """Packed RAW (MSB-first 10/12/14/16-bit) -> u16 CFA plane on the device (rpf_dev_unpack_bayer)."""
-    _check(N.lib().rpf_dev_unpack_bayer(processor._h, C.c_void_p(d_packed_ptr), row_stride, width, rows, bits,
+                     d_cfa_ptr: int, stream: int = 0, order: int = N.PACK_MSB_FIRST) -> None:
+    """Packed RAW (10/12/14/16-bit, MSB- or LSB-first) -> u16 CFA plane on the device (rpf_dev_unpack_bayer)."""
+    _check(N.lib().rpf_dev_unpack_bayer(processor._h, C.c_void_p(d_packed_ptr), row_stride, width, rows, bits, order,
                                         C.c_void_p(d_cfa_ptr), C.c_void_p(stream)))

@@ -13,6 +13,24 @@ def test_oracle_known_answers():
     assert O.unpack_bayer(np.array([[0x12, 0x34, 0xAB, 0xCD]], np.uint8), 2, 16).tolist() == [[0x1234, 0xABCD]]
 
 
+def test_oracle_known_answers_lsb_first():
+    # 12-bit little-endian: samples ABC, DEF -> bytes BC, FA, DE;  10-bit: 3FF, 000, 000, 001 -> FF 03 00 40 00
+    L = O.PACK_LSB_FIRST
+    assert O.pack_bayer(np.array([[0xABC, 0xDEF]], np.uint16), 12, order=L)[0, :3].tolist() == [0xBC, 0xFA, 0xDE]
+    assert O.unpack_bayer(np.array([[0xBC, 0xFA, 0xDE, 0]], np.uint8), 2, 12, order=L).tolist() == [[0xABC, 0xDEF]]
+    assert O.unpack_bayer(np.array([[0xFF, 0x03, 0x00, 0x40, 0x00, 0, 0, 0]], np.uint8), 4, 10, order=L).tolist() == [[1023, 0, 0, 1]]
+    assert O.unpack_bayer(np.array([[0x34, 0x12, 0xCD, 0xAB]], np.uint8), 2, 16, order=L).tolist() == [[0x1234, 0xABCD]]
+    rng = np.random.default_rng(5)
+    for bits in (10, 12, 14, 16):
+        for w in (1, 15, 17, 100):
+            a = rng.integers(0, 1 << bits, (5, w), dtype=np.uint16)
+            p = O.pack_bayer(a, bits, order=L)
+            assert np.array_equal(O.unpack_bayer(p, w, bits, order=L), a)
+            # numpy cross-check: little-endian bit matrix
+            bitsm = np.unpackbits(p, axis=1, bitorder="little")[:, :w * bits].reshape(5, w, bits)
+            assert np.array_equal((bitsm * (1 << np.arange(bits))).sum(-1), a)
+
+
 @pytest.mark.parametrize("bits", [10, 12, 14, 16])
 def test_oracle_round_trip(bits):
     rng = np.random.default_rng(bits)
@@ -26,18 +44,20 @@ def test_oracle_round_trip(bits):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("bits", [10, 12, 14, 16])
-def test_gpu_unpack_bit_exact(gpu, bits):
+def test_gpu_unpack_bit_exact(gpu, bits, order):
     torch = pytest.importorskip("torch")
     import rawphotoforge_amd as R
     rng = np.random.default_rng(100 + bits)
     for h, w, extra in ((9, 64, 0), (5, 1000, 0), (4, 37, 0), (3, 16, 4), (6, 6000, 0), (2, 15, 0), (3, 24, 3)):
         a = rng.integers(0, 1 << bits, (h, w), dtype=np.uint16)
         stride = O.packed_row_stride(w, bits) + extra          # `extra` = 3 makes rows unaligned (slow path)
-        p = O.pack_bayer(a, bits, stride)
+        p = O.pack_bayer(a, bits, stride, order=order)
         d = torch.from_numpy(p).cuda()
         out = torch.zeros((h, w), dtype=torch.int16, device="cuda")
-        R.dev_unpack_bayer(gpu, d.data_ptr(), stride, w, h, bits, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        R.dev_unpack_bayer(gpu, d.data_ptr(), stride, w, h, bits, out.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                           order=order)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint16), a), (h, w, extra)
 
@@ -72,8 +92,9 @@ def test_gpu_unpack_rejects_bad_arguments(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("bits", [10, 12, 14, 16])
-def test_gpu_fused_unpack_develop_bit_exact(gpu, bits):
+def test_gpu_fused_unpack_develop_bit_exact(gpu, bits, order):
     """rpf_dev_develop_packed == unpack (oracle, integer) followed by the oracle's develop, on whole frames and on row
     bands with halo rows, ragged widths, padded / odd row strides, all three output layouts."""
     torch = pytest.importorskip("torch")
@@ -91,20 +112,20 @@ def test_gpu_fused_unpack_develop_bit_exact(gpu, bits):
         # whole frame: halo rows exist in the buffer but are never read (reflect-101 at the frame edge)
         pad = np.zeros((h + 4, w), np.uint16)
         pad[2:-2] = cfa
-        d = torch.from_numpy(O.pack_bayer(pad, bits, stride)).cuda()
+        d = torch.from_numpy(O.pack_bayer(pad, bits, stride, order=order)).cuda()
         ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
         util.configure_editor(ed, p)
         out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
-        ed.dev_develop_packed(d.data_ptr(), stride, bits, util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32, s)
+        ed.dev_develop_packed(d.data_ptr(), stride, bits, util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32, s, order=order)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (h, w, extra, pname)
         if h >= 24:   # a row band in the middle: its halo rows are real neighbours
             y0, rows = 8, h - 14
-            band = torch.from_numpy(O.pack_bayer(cfa[y0 - 2:y0 + rows + 2], bits, stride)).cuda()
+            band = torch.from_numpy(O.pack_bayer(cfa[y0 - 2:y0 + rows + 2], bits, stride, order=order)).cuda()
             et = R.PhotoEditor.for_tile(gpu, w, h, y0, rows)
             util.configure_editor(et, p)
             o8 = torch.empty((rows, w, 3), dtype=torch.uint8, device="cuda")
-            et.dev_develop_packed(band.data_ptr(), stride, bits, util.to_raw(rp), o8.data_ptr(), R.OUT_RGB_U8, s)
+            et.dev_develop_packed(band.data_ptr(), stride, bits, util.to_raw(rp), o8.data_ptr(), R.OUT_RGB_U8, s, order=order)
             torch.cuda.synchronize()
             ref8 = (np.clip(want[y0:y0 + rows, :, :3], 0, 1) * np.float32(255.0)).astype(np.uint8)
             assert np.array_equal(o8.cpu().numpy(), ref8)
