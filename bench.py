@@ -115,6 +115,8 @@ def main():
         host_packed = syn.pack_msb(band.cpu().numpy().view(np.uint16), 14)
         packed_stride = host_packed.shape[1]
         packed_band = torch.from_numpy(host_packed).cuda()
+        dev_packed = tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, configure, rank, world,
+                                         overlap=not args.no_overlap, packed=(14, packed_stride, R.PACK_MSB_FIRST))
     stream = torch.cuda.current_stream().cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -122,12 +124,13 @@ def main():
         if args.workload == "develop":   # halo exchange (N > 1) hidden behind the interior rows
             dev.step(band, out, out_fmt, out_bpp, True, ev[i] if i is not None else None)
             return
+        if args.workload == "develop_packed":   # the same on the packed band (its halo rows are packed rows too)
+            dev_packed.step(packed_band, out, R.OUT_RGBA_F32, 16, True, ev[i] if i is not None else None)
+            return
         tiles.exchange_halos(band, rank, world)          # no-op at N = 1
         if i is not None:
             ev[i][0].record()
-        if args.workload == "develop_packed":
-            ed.dev_develop_packed(packed_band.data_ptr(), packed_stride, 14, praw_c, out.data_ptr(), R.OUT_RGBA_F32, stream)
-        elif args.workload == "unpack":
+        if args.workload == "unpack":
             R.dev_unpack_bayer(gpu, packed.data_ptr(), packed.shape[1], W, rows, 12, band[2:].data_ptr(), stream)
         elif args.workload == "demosaic":
             R.dev_demosaic(gpu, band.data_ptr(), praw, W, frame_h, y0, rows, out.data_ptr(), stream)
@@ -164,7 +167,8 @@ def main():
     mp_per_step = world * rows * W / 1e6
     value = mp_per_step * args.steps / dt
     bpp = BYTES_PER_PX[args.workload] if args.out == "rgba" else 2 + out_bpp
-    timed_rows = dev.parts[0][1] if args.workload == "develop" else rows   # the launch the events bracket
+    timed_rows = (dev.parts[0][1] if args.workload == "develop" else
+                  dev_packed.parts[0][1] if args.workload == "develop_packed" else rows)   # the launch the events bracket
     achieved = bpp * timed_rows * W / (kern_avg_ms * 1e-3) / 1e9   # GB/s, algorithmic bytes of ONE launch
 
     result = {

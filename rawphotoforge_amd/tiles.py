@@ -93,12 +93,15 @@ class BandDeveloper:
     EDGE = 8  # rows per edge tile = one work item of the kernel (64 columns x 8 rows)
 
     def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, rank=0, world=1, overlap=True,
-                 force_split=False, schedule="side"):
+                 force_split=False, schedule="side", packed=None):
         import torch
 
         from .editor import PhotoEditor
 
         self.raw = raw.to_c() if hasattr(raw, "to_c") else raw  # converted once, not per launch
+        # packed = (bits, row_stride_bytes, order): the band buffer holds bit-packed rows (uint8, (rows + 4) x row_stride)
+        # and the fused kernel unpacks them itself (rpf_dev_develop_packed)
+        self.packed = packed
         self.rank, self.world = rank, world
         self._ops_for = None  # (band tensor id, data_ptr) the cached P2P op list belongs to
         self._ops = None
@@ -123,18 +126,26 @@ class BandDeveloper:
             self._torch.cuda.current_stream().wait_stream(self.side)
 
     def step(self, band, out, out_format=0, bytes_per_px=16, exchange=True, events=None):
-        """band: (rows + 4, W) 2-byte tensor with halo rows; out: rows x W pixels.  `events`: optional
+        """band: (rows + 4, W) 2-byte tensor with halo rows (packed: (rows + 4, row_stride) uint8); out: rows x W pixels.  `events`: optional
         (start, end) CUDA events recorded around the dominant (interior / whole-band) launch."""
         import torch.distributed as dist
 
         cur = self._torch.cuda.current_stream()
         stream = cur.cuda_stream
         bptr, optr = band.data_ptr(), out.data_ptr()
-        row_in, row_out = self.w * 2, self.w * bytes_per_px
+        row_in, row_out = (self.packed[1] if self.packed else self.w * 2), self.w * bytes_per_px
+
+        def launch_on(part, on_stream):
+            off, _, ed = part
+            if self.packed:
+                bits, stride, order = self.packed
+                ed.dev_develop_packed(bptr + off * row_in, stride, bits, self.raw, optr + off * row_out, out_format,
+                                      on_stream, order)
+            else:
+                ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, on_stream)
 
         def launch(part):
-            off, _, ed = part
-            ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, stream)
+            launch_on(part, stream)
 
         if self.side is not None:
             # exchange + edge tiles on the side stream, gated on what the current stream held BEFORE the interior
@@ -155,8 +166,7 @@ class BandDeveloper:
                     for r in dist.batch_isend_irecv(self._ops):
                         r.wait()
                 for part in self.parts[1:]:
-                    off, _, ed = part
-                    ed.dev_develop(bptr + off * row_in, self.raw, optr + off * row_out, out_format, sstream)
+                    launch_on(part, sstream)
             if self.schedule != "pipelined":
                 cur.wait_stream(self.side)
             return

@@ -49,6 +49,25 @@ for schedule in ("side", "serial", "pipelined"):
         print(f"rank {rank}/{world} schedule {schedule} frame {frame}: rows [{y0}, {y0 + rows}) "
               f"{'bit-identical to the oracle' if same else 'MISMATCH'}", flush=True)
         dist.barrier()
+# the same with a packed band (12-bit LSB-first): the halo rows exchanged are packed rows
+bits, order = 12, R.PACK_LSB_FIRST
+rp12 = O.RawParams(black=(200,) * 4, white=4095)
+cfa = syn.bayer_natural(H, W, seed=600) & 0x0FFF
+pad = np.zeros((rows + 4, W), np.uint16)
+pad[2:-2] = cfa[y0:y0 + rows]
+stride = O.packed_row_stride(W, bits)
+pband = torch.from_numpy(O.pack_bayer(pad, bits, stride, order=order)).cuda()
+devp = tiles.BandDeveloper(gpu, W, H, y0, rows, util.to_raw(rp12), lambda e: syn.configure(e, spec), rank, world,
+                           packed=(bits, stride, order))
+out = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
+dist.barrier()
+for _ in range(2):
+    devp.step(pband, out)
+torch.cuda.synchronize()
+same = np.array_equal(out.cpu().numpy().view(np.uint32), O.develop(cfa, rp12, [p], y0=y0, rows=rows).view(np.uint32))
+ok = ok and same
+print(f"rank {rank}/{world} packed 12-bit LSB-first band: {'bit-identical to the oracle' if same else 'MISMATCH'}", flush=True)
+dist.barrier()
 t = torch.tensor([1.0 if ok else 0.0], device="cuda")
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
 if rank == 0:
