@@ -38,7 +38,10 @@
  *     throws or aborts across this boundary.
  *   - host pointers are borrowed for the duration of the call only.
  *   - an editor is externally synchronised (one thread at a time, like `&mut self`);
- *     a processor may be shared by several editors and must outlive them.
+ *     a processor may be shared by several editors.  It is reference counted like the
+ *     reference's Arc<GpuProcessor> (lib.rs:83): rpf_processor_destroy releases the caller's
+ *     handle, and the device tables live until the last editor created on it is destroyed.
+ *     (After rpf_processor_destroy the handle must not be passed to rpf_* again.)
  *   - rpf_apply_adjustments enqueues on the editor's HIP stream and returns;
  *     rpf_get_* / rpf_editor_sync wait (reference: submit returns before the GPU
  *     finishes, readback blocks; gpu_image_processing.rs:391-399, image.rs:249-259).
@@ -117,7 +120,7 @@ const char* rpf_version(void);
 int rpf_device_count(int* count);
 int rpf_device_name(int device, char* buf, size_t buf_len); /* get_adapter_string_list */
 int rpf_processor_create(int device, rpf_processor** out);  /* GpuProcessor::new(adapter_index) */
-void rpf_processor_destroy(rpf_processor* p);
+void rpf_processor_destroy(rpf_processor* p);                /* drop(Arc<GpuProcessor>): editors keep it alive */
 int rpf_processor_device(const rpf_processor* p, int* device);
 int rpf_processor_compute_units(const rpf_processor* p, int* cus);
 

@@ -46,8 +46,8 @@ static int fail_exception() noexcept
     try {
         throw;
     } catch (const std::bad_alloc&) {
-        try { g_last_error = "out of host memory"; } catch (...) {}
-        return RPF_ERR_INVALID_ARGUMENT;
+        try { g_last_error = "GPU compute error: out of host memory"; } catch (...) {}
+        return RPF_ERR_GPU_COMPUTE;  // a resource failure, not a caller mistake
     } catch (const std::exception& ex) {
         try { g_last_error = std::string("internal error: ") + ex.what(); } catch (...) {}
         return RPF_ERR_GPU_COMPUTE;
@@ -76,8 +76,22 @@ struct rpf_processor {
     LegacyTables* d_legacy = nullptr;  // Godot-legacy flavour only
     HueBound* d_hue_bounds = nullptr;  // 65536 entries, 1 MiB
     HueBoundCs* d_hue_cs = nullptr;    // 65536 entries, 2 MiB (HUE_DIRECT launches)
-    std::atomic<int> editors{0};
+    // Arc<GpuProcessor> (lib.rs:83): one reference for the caller's handle plus one per editor created on it.
+    // rpf_processor_destroy drops the caller's; the device tables are freed by whoever drops the last one.
+    std::atomic<int> refs{1};
 };
+
+static void processor_unref(rpf_processor* p)
+{
+    if (p->refs.fetch_sub(1) != 1) return;
+    if (hipSetDevice(p->device) == hipSuccess) {
+        if (p->d_tabs) (void)hipFree(p->d_tabs);
+        if (p->d_legacy) (void)hipFree(p->d_legacy);
+        if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
+        if (p->d_hue_cs) (void)hipFree(p->d_hue_cs);
+    }
+    delete p;
+}
 
 struct CurveStamps {
     uint64_t v[4];
@@ -326,13 +340,7 @@ int rpf_processor_create(int device, rpf_processor** out)
 void rpf_processor_destroy(rpf_processor* p)
 {
     if (!p) return;
-    if (hipSetDevice(p->device) == hipSuccess) {
-        if (p->d_tabs) (void)hipFree(p->d_tabs);
-        if (p->d_legacy) (void)hipFree(p->d_legacy);
-        if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
-        if (p->d_hue_cs) (void)hipFree(p->d_hue_cs);
-    }
-    delete p;
+    processor_unref(p);  // editors still alive keep the tables until the last of them is destroyed
 }
 
 int rpf_processor_device(const rpf_processor* p, int* device)
@@ -361,9 +369,9 @@ int rpf_set_kernel_variant(rpf_processor* p, int variant)
 static int editor_device_init(rpf_editor* e, rpf_processor* p)
 {
     e->proc = p;
+    p->refs.fetch_add(1);  // dropped by rpf_editor_destroy, also on the failure paths below
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    p->editors.fetch_add(1);
     return ok();
 }
 
@@ -376,8 +384,8 @@ void rpf_editor_destroy(rpf_editor* e)
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         if (e->stream) (void)hipStreamDestroy(e->stream);
-        e->proc->editors.fetch_sub(1);
     }
+    if (e->proc) processor_unref(e->proc);
     delete e;
 }
 

@@ -9,20 +9,23 @@
 // Replaces rust/photo-editor/src/wgpu_shader.wgsl:265-337 (kernel) and the dispatch half of
 // rust/photo-editor/src/gpu_image_processing.rs:214-400.  Not a translation of the WGSL
 // 16x16 one-thread-per-texel pass:
-//   * k_stream: a wavefront owns a 60-column strip and walks down it two rows at a time.  Each lane keeps
-//     a rolling 6-row window of ITS column in registers (two coalesced 128-B row loads per step, every CFA
+//   * k_stream: a wavefront owns a 64-column strip (STRIP_W) and walks down it two rows at a time.  Each lane
+//     keeps a rolling 6-row window of ITS column in registers (two coalesced 128-B row loads per step, every CFA
 //     sample normalised once), takes the horizontal taps of the 5x5 stencil from its neighbours with DPP
 //     wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) and carries the horizontal pair sums of a
-//     row down the window, so the stencil costs no LDS traffic and no barrier at all.  Lanes 0,1,62,63 are
-//     the strip's apron (64 loaded columns -> 60 outputs).
+//     row down the window, so the stencil costs no LDS traffic and no barrier at all.  The four samples per row
+//     beyond the wavefront's 64 columns come from one extra "halo" load per row, held by lanes 0,1 (columns
+//     x0-2, x0-1) and 62,63 (x0+64, x0+65): all 64 lanes produce output.
 //   * a vertical pixel pair always holds one R/B site and one G site, so both demosaic formula sets run
 //     without divergence, and the pair goes through the edit chain in lockstep (rpf_chain.h);
 //   * the transcendental tables (28 KiB) and, when it is not the identity, the 65536-entry brightness
 //     curve (u16, 128 KiB) are staged in LDS once per workgroup, so curve gathers never leave the CU;
-//   * every store is a global_store_dwordx4, 960 B contiguous per wave-instruction.
+//   * every store is a nontemporal global_store_dwordx4, one aligned KiB per wave-instruction.
 // Pointwise/stencil path: HBM-bound by construction, no MFMA.
 #include <hip/hip_runtime.h>
 #include <string.h>
+
+#include <atomic>
 
 #include "rpf_launch.h"
 
@@ -741,13 +744,15 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     // to one 1024-thread workgroup per CU
     uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
     if (MODE != MODE_DEMOSAIC) {  // never more than are resident (a register count over 96 would halve the last round)
-        static int resident[2] = {0, 0};  // per build (without / with the vignette stage)
-        if (resident[vign] == 0) {
-            int nb = 0;
+        // per build (without / with the vignette stage); atomic: two host threads may launch for the first time
+        // together (both then store the same value)
+        static std::atomic<int> resident[2];
+        int nb = resident[vign].load(std::memory_order_relaxed);
+        if (nb == 0) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NT, lds) != hipSuccess || nb < 1) nb = 1;
-            resident[vign] = nb;
+            resident[vign].store(nb, std::memory_order_relaxed);
         }
-        if (per_cu > (uint32_t)resident[vign]) per_cu = (uint32_t)resident[vign];
+        if (per_cu > (uint32_t)nb) per_cu = (uint32_t)nb;
     }
     const uint32_t cap_waves = (uint32_t)cfg.num_cus * per_cu * WPB;
     auto items_for = [&](uint32_t sp) { return a.strips * ((total_pairs + sp - 1) / sp); };
@@ -906,11 +911,11 @@ static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
     const size_t npix = (size_t)a.g.rows * a.g.width;
     // persistent grid-stride workgroups: exactly as many as are resident (registers and the 28-KiB table copy in
     // LDS decide; one more per CU would run as a second, mostly empty round)
-    static int resident = 0;
+    static std::atomic<int> resident_cache;
+    int resident = resident_cache.load(std::memory_order_relaxed);
     if (resident == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NT, lds) != hipSuccess || nb < 1) nb = 1;
-        resident = nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, NT, lds) != hipSuccess || resident < 1) resident = 1;
+        resident_cache.store(resident, std::memory_order_relaxed);
     }
     size_t grid = (size_t)cfg.num_cus * (size_t)resident;
     const size_t need = (npix + NT * 2 - 1) / (NT * 2);

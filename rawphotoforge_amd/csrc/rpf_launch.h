@@ -41,14 +41,15 @@ hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const Ra
                            float* d_rgba, hipStream_t s);
 hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                           const DeviceEdit& ed, void* d_out, int out_format, hipStream_t s);
-// the same with the integer unpack folded in: d_packed holds (rows + 4) MSB-first bit-packed rows (10/12/14/16 bits)
+// the same with the integer unpack folded in: d_packed holds (rows + 4) bit-packed rows (10/12/14/16 bits), `order` =
+// RPF_PACK_MSB_FIRST (big-endian bit stream) or RPF_PACK_LSB_FIRST (little-endian)
 hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, uint32_t row_stride, uint32_t bits,
                                  uint32_t order, const RawParamsDev& raw, const TileGeom& g, const DeviceEdit& ed, void* d_out,
                                  int out_format, hipStream_t s);
 // d_in: rows x width RGBA32F (whole frame when lens_strength != 0)
 hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom& g, const DeviceEdit& ed, void* d_out,
                         int out_format, hipStream_t s);
-// packed RAW (MSB-first bit stream, 10/12/14/16 bits) -> u16 plane of pitch `width`
+// packed RAW (10/12/14/16 bits, MSB-first or LSB-first bit stream per `order`) -> u16 plane of pitch `width`
 hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows, uint32_t bits,
                          uint32_t order, uint16_t* d_out, hipStream_t s);
 // bilinear resize of the preview pyramid (web/main.ts:958-1026), RGBA32F -> RGBA32F

@@ -75,6 +75,29 @@ def make_band_buffer(cfa_band, device=None):
     return t.to(device) if device is not None else t
 
 
+class _PartEditor:
+    """What BandDeveloper hands to the `configure` callback: the editor of ONE part (row range) of the band.
+
+    Every attribute is the part's own PhotoEditor's, except add_mask: the callback describes the band, so a
+    band-sized mask (band_rows x W) is cut to the part's rows here (lib.rs:481-499 takes a whole-image mask; the
+    band is this rank's image).  A mask that already has the part's size is passed through unchanged.
+    """
+
+    def __init__(self, ed, off, n, band_rows, width):
+        self._ed, self._off, self._n, self._band_rows, self._w = ed, off, n, band_rows, width
+
+    def __getattr__(self, name):
+        return getattr(self._ed, name)
+
+    def add_mask(self, name, mask_data):
+        import numpy as np
+
+        m = np.asarray(mask_data, dtype=np.float32)
+        if m.size == self._band_rows * self._w and self._band_rows != self._n:
+            m = m.reshape(self._band_rows, self._w)[self._off:self._off + self._n]
+        self._ed.add_mask(name, m)
+
+
 class BandDeveloper:
     """One rank's band of a row-tiled frame through the fused kernel, with the halo exchange hidden
     behind the interior rows.
@@ -88,6 +111,10 @@ class BandDeveloper:
     kernels then sit between consecutive interiors; "pipelined" (no per-step join: call join() before reading
     the output) +0 %.  With world == 1 (or overlap=False) it is one launch.
     All three tiles are views of the same band / output buffers (rpf_dev_develop takes raw pointers).
+
+    `configure(ed)` sets up the edit state; it is called once per part with a view of that part's editor on which
+    `add_mask(name, mask)` accepts a mask of the whole BAND (rows x W) and keeps the part's rows of it, so the same
+    callback serves the single launch and the three-launch split.
     """
 
     EDGE = 8  # rows per edge tile = one work item of the kernel (64 columns x 8 rows)
@@ -114,7 +141,7 @@ class BandDeveloper:
         self.parts = []
         for off, n in parts:  # (row offset inside the band, rows): interior first
             ed = PhotoEditor.for_tile(gpu, frame_width, frame_height, y0 + off, n)
-            configure(ed)
+            configure(_PartEditor(ed, off, n, rows, frame_width))
             self.parts.append((off, n, ed))
         self.schedule = schedule
         self.side = torch.cuda.Stream() if self.split and schedule != "serial" else None

@@ -315,6 +315,61 @@ def test_band_developer_overlap_split_equals_oracle(gpu):
         assert torch.equal(out, out2)
 
 
+def test_band_developer_split_with_user_masks(gpu):
+    """User masks on a split band: the configure callback adds BAND-sized masks, every part (interior, two edge
+    tiles) gets its rows of them; the three launches must equal the oracle's whole-frame answer on the band."""
+    torch = pytest.importorskip("torch")
+    from rawphotoforge_amd import tiles
+    h, w = 200, 140
+    cfa = util.bayer_uniform(h, w, seed=5)
+    rp = util.raw_params()
+    rng = np.random.default_rng(21)
+    main, a, b = util.params_D(), util.params_S(), util.params_G()
+    ma = np.where(rng.random((h, w)) > 0.5, 1.0, -1.0).astype(np.float32)
+    mb = np.full((h, w), -1.0, np.float32)
+    mb[4:150, 30:120] = 1.0   # crosses the band boundary and both edge tiles of band 1
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(ma), O.binarize_mask(mb)])
+    want = O.develop(cfa, rp, [main, a, b], masks=masks)
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    for rank, (y0, rows) in enumerate(((0, 90), (90, 110))):
+        def configure(e, y0=y0, rows=rows):
+            e.add_mask("a", ma[y0:y0 + rows])
+            e.add_mask("b", mb[y0:y0 + rows].reshape(-1))
+            util.configure_editor(e, main)
+            util.configure_editor(e, a, "a", main=False)
+            util.configure_editor(e, b, "b", main=False)
+        band = torch.from_numpy(pad[y0:y0 + rows + 4].copy().view(np.int16)).cuda()
+        out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+        bd = tiles.BandDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), configure, rank=rank, world=2, overlap=True)
+        assert bd.split and all(ed.num_masks == 3 for _, _, ed in bd.parts)
+        bd.step(band, out, R.OUT_RGBA_F32, 16, exchange=False)
+        torch.cuda.synchronize()
+        assert_parity(out.cpu().numpy(), want[y0:y0 + rows])
+
+
+def test_processor_outlives_its_handle_while_editors_exist():
+    """Arc<GpuProcessor> (lib.rs:83): destroying the processor handle first must not pull the device tables from
+    under an editor that still uses them (use-after-free for a C caller)."""
+    import ctypes as C
+    from rawphotoforge_amd import _native as N
+    lib = N.lib()
+    proc = C.c_void_p()
+    assert lib.rpf_processor_create(0, C.byref(proc)) == 0
+    h, w = 24, 40
+    cfa = util.bayer_uniform(h, w, seed=3)
+    rp = util.to_raw(util.raw_params()).to_c()
+    ed = C.c_void_p()
+    assert lib.rpf_editor_create_from_bayer_u16(proc, cfa.ctypes.data_as(C.POINTER(C.c_uint16)), w, h, C.byref(rp),
+                                                C.byref(ed)) == 0
+    lib.rpf_processor_destroy(proc)            # the caller's handle goes first
+    assert lib.rpf_apply_adjustments(ed) == 0  # tables are still there
+    out = np.zeros((h, w, 4), np.float32)
+    assert lib.rpf_get_rgba_f32(ed, out.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert_parity(out, O.develop(cfa, util.raw_params(), [O.EditParameters()]))
+    lib.rpf_editor_destroy(ed)                 # last reference: frees the processor
+
+
 def test_empty_and_invalid_inputs(gpu):
     with pytest.raises(R.FailedToReadImage):
         R.PhotoEditor.new_from_rgb_f32(gpu, np.zeros(0, np.float32), 0, 0)

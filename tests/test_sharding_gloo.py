@@ -80,3 +80,31 @@ def test_split_rows():
         assert all(bands[i][0] + bands[i][1] == bands[i + 1][0] for i in range(n - 1))
     with pytest.raises(ValueError):
         tiles.split_rows(6, 4)
+
+
+def test_part_editor_cuts_band_masks_to_its_rows():
+    """BandDeveloper's configure callback describes the BAND; each part's editor must receive its own rows of a
+    band-sized mask (masks could not be combined with the three-launch split)."""
+    class FakeEditor:
+        def __init__(self):
+            self.masks, self.tone = {}, None
+
+        def add_mask(self, name, m):
+            self.masks[name] = np.array(m)
+
+        def set_tone(self, *a):
+            self.tone = a
+
+    rows, w = 40, 6
+    mask = np.arange(rows * w, dtype=np.float32).reshape(rows, w)
+    for off, n in ((8, 24), (0, 8), (32, 8), (0, rows)):
+        fe = FakeEditor()
+        pe = tiles._PartEditor(fe, off, n, rows, w)
+        pe.add_mask("m", mask)                 # band-sized: cut
+        pe.add_mask("flat", mask.reshape(-1))  # flat band-sized vector: cut as well
+        pe.set_tone(1, 2, 3)                   # everything else goes straight through
+        assert fe.tone == (1, 2, 3)
+        assert np.array_equal(fe.masks["m"], mask[off:off + n])
+        assert np.array_equal(fe.masks["flat"].reshape(-1), mask[off:off + n].reshape(-1))
+        pe.add_mask("own", mask[off:off + n])  # already part-sized: unchanged
+        assert np.array_equal(fe.masks["own"], mask[off:off + n])
