@@ -100,7 +100,7 @@ RPF_HD float vignette_axis2(int i, float n)
 }
 RPF_HD float vignette_from_axes(float vign_strength, float cx2, float cy2)
 {
-    const float dist = __builtin_sqrtf(cx2 + cy2);
+    const float dist = sqrt_cr(cx2 + cy2);
     // (dist - 0.25) / 0.75 by Markstein's sequence: equal to the IEEE quotient (every binary32 in [-0.25, 2] checked,
     // tests/test_math_exhaustive.py)
     const float t = div_by_const(dist - 0.25f, 0.75f, (float)(1.0 / 0.75));
@@ -200,43 +200,54 @@ RPF_HD float max0(float v)
 #endif
 }
 
+// The flag word of a mask whose every stage is the reference default (lib.rs:44-64: a photo that was just opened,
+// BASELINE's edit set D): nothing to multiply, identity / constant curves.  Kernels instantiated with
+// STATIC_FLAGS = MF_PRISTINE know all of this at compile time; STATIC_FLAGS < 0 reads the flags at run time.
+constexpr uint32_t MF_PRISTINE = MF_BRIGHT_IDENTITY | MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST | MF_UNITY_WB |
+                                 MF_UNITY_EXPOSURE | MF_NO_SHADOW_HIGHLIGHT;
+
 // One mask's linear-RGB stage (wgsl:283-307) on N pixels in lockstep.  act == nullptr: the mask is
 // "main" (all ones); otherwise pixel n is updated only where act[n] is set (wgsl:281 `continue`).
-template <int N, class Luts>
-RPF_HD void mask_rgb_stage(const MaskParams& P, uint32_t m, const Luts& luts, float (&r)[N], float (&g)[N],
+template <int N, int STATIC_FLAGS = -1, class Luts>
+RPF_HD void mask_rgb_stage(const MaskParams& PP, uint32_t m, const Luts& luts, float (&r)[N], float (&g)[N],
                            float (&b)[N], const bool* act)
 {
+    struct Flags { uint32_t flags; };
+    const Flags P{STATIC_FLAGS >= 0 ? (uint32_t)STATIC_FLAGS : PP.flags};
     const float inv65535 = (float)(1.0 / 65535.0);
     for (int n = 0; n < N; ++n) {
         float x = r[n], y = g[n], z = b[n];
-        if (!(P.flags & MF_UNITY_WB)) { x *= P.r_gain; y *= P.g_gain; z *= P.b_gain; }  // wgsl:285-288
+        // White balance (wgsl:285-288) and exposure (wgsl:214-215).  x * 1.0f == x exactly, so the unity flags only
+        // matter where they are known at compile time: tested at run time the compiler executes the multiplications
+        // anyway and adds a select each (measured: 12 + 12 half-rate instructions per pixel pair).
+        if (STATIC_FLAGS < 0 || !(P.flags & MF_UNITY_WB)) { x *= PP.r_gain; y *= PP.g_gain; z *= PP.b_gain; }
         // tone(), wgsl:200-259
-        if (!(P.flags & MF_UNITY_EXPOSURE)) { x *= P.exposure_mul; y *= P.exposure_mul; z *= P.exposure_mul; }
+        if (STATIC_FLAGS < 0 || !(P.flags & MF_UNITY_EXPOSURE)) { x *= PP.exposure_mul; y *= PP.exposure_mul; z *= PP.exposure_mul; }
         float highlight_mask = 0.0f;
         if ((P.flags & (MF_NO_SHADOW_HIGHLIGHT | MF_BLACK | MF_WHITE)) != MF_NO_SHADOW_HIGHLIGHT) {
             const float luma = x * RPF_F(0.2126) + y * RPF_F(0.7152) + z * RPF_F(0.0722);
             highlight_mask = clamp01(luma);
             if (!(P.flags & MF_NO_SHADOW_HIGHLIGHT)) {
                 const float shadow_mask = clamp01(1.0f - luma);
-                const float shadow_gain = 1.0f + P.shadow * shadow_mask;
+                const float shadow_gain = 1.0f + PP.shadow * shadow_mask;
                 x *= shadow_gain; y *= shadow_gain; z *= shadow_gain;
-                const float highlight_gain = 1.0f + P.highlight * highlight_mask;
+                const float highlight_gain = 1.0f + PP.highlight * highlight_mask;
                 x *= highlight_gain; y *= highlight_gain; z *= highlight_gain;
             }
         }
         if (P.flags & MF_BLACK) {
             const float t1 = 1.0f - highlight_mask;
-            const float add = P.black * (t1 * t1);  // pow(1 - t, 2.0) correctly rounded
+            const float add = PP.black * (t1 * t1);  // pow(1 - t, 2.0) correctly rounded
             x += add; y += add; z += add;
         }
         if (P.flags & MF_WHITE) {
-            const float add = P.white * (highlight_mask * highlight_mask);
+            const float add = PP.white * (highlight_mask * highlight_mask);
             x += add; y += add; z += add;
         }
         if (P.flags & MF_CONTRAST) {
-            x = (x - 0.5f) * P.contrast_c + 0.5f;
-            y = (y - 0.5f) * P.contrast_c + 0.5f;
-            z = (z - 0.5f) * P.contrast_c + 0.5f;
+            x = (x - 0.5f) * PP.contrast_c + 0.5f;
+            y = (y - 0.5f) * PP.contrast_c + 0.5f;
+            z = (z - 0.5f) * PP.contrast_c + 0.5f;
         }
         x = clamp01(x); y = clamp01(y); z = clamp01(z);
         // brightness curve, wgsl:293-305
@@ -263,12 +274,13 @@ RPF_HD void mask_rgb_stage(const MaskParams& P, uint32_t m, const Luts& luts, fl
 // HUE_DIRECT (the caller's promise: num_masks == 1 and "main"'s hue curve is the identity): the index the hue
 // becomes IS the new hue, and cos / sin of its angle come with the boundary-table entry (hue_index_cs) instead of
 // being evaluated by sincos_hue.  A compile-time choice: as a run-time branch it splits the pair's gathers again.
-template <int N, bool HUE_DIRECT = false, class Luts, class Tabs>
+// STATIC_FLAGS (>= 0): "main"'s flag word, known at compile time (the caller's promise that mp[0].flags equals it).
+template <int N, bool HUE_DIRECT = false, int STATIC_FLAGS = -1, class Luts, class Tabs>
 RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],
                        const MaskParams* mp, uint32_t num_masks, const Luts& luts, const Tabs& T)
 {
     const float inv65535 = (float)(1.0 / 65535.0);
-    mask_rgb_stage<N>(mp[0], 0u, luts, r, g, b, nullptr);  // "main" is all ones (lib.rs:193-196)
+    mask_rgb_stage<N, STATIC_FLAGS>(mp[0], 0u, luts, r, g, b, nullptr);  // "main" is all ones (lib.rs:193-196)
     // bits of the user masks that cover at least one pixel of this wavefront: a mask that covers none is skipped
     // as a whole (wgsl:281 `continue` for every lane) — masks are regions, most wavefronts lie inside or outside
     uint32_t any_active = 0;
@@ -303,7 +315,7 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         L[n] = RPF_F(0.2104542553) * lc + RPF_F(0.7936177850) * mc + RPF_F(-0.0040720468) * sc;
         const float A = RPF_F(1.9779984951) * lc + RPF_F(-2.4285922050) * mc + RPF_F(0.4505937099) * sc;
         const float Bq = RPF_F(0.0259040371) * lc + RPF_F(0.7827717662) * mc + RPF_F(-0.8086757660) * sc;
-        C[n] = __builtin_sqrtf(A * A + Bq * Bq);
+        C[n] = sqrt_cr(A * A + Bq * Bq);
         // u32(h * 65535), h = atan2(b, a) / (2 pi) wrapped (wgsl:72-73, 320)
         if (HUE_DIRECT) {
             hu0[n] = hue_index_cs(Bq, A, luts.hue_bounds_cs(), T.sc, cs0[n], sn0[n]);
@@ -317,7 +329,8 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
     uint32_t hue_k[N];
     auto oklch_stage = [&](uint32_t m, bool main_mask) {
         const MaskParams& P = mp[m];
-        const bool trivial = (P.flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
+        const uint32_t pflags = (main_mask && STATIC_FLAGS >= 0) ? (uint32_t)STATIC_FLAGS : P.flags;
+        const bool trivial = (pflags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
                              (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
         for (int n = 0; n < N; ++n) {
             const uint32_t hu = main_mask ? hu0[n] : (uint32_t)(h[n] * 65535.0f);
@@ -351,8 +364,11 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         float out[3];
         for (int k = 0; k < 3; ++k) {
             const float c = lin[k];
-            const float hi = RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - RPF_F(0.055);  // unused when c <= thr
-            out[k] = clamp01(c <= RPF_F(0.0031308) ? c * RPF_F(12.92) : hi);
+            // clamp(select(a, b)) == select(clamp(a), clamp(b)); written this way each clamp is the free output
+            // modifier of the multiplication / addition in front of it instead of a v_max of its own
+            const float hi = clamp01(RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - RPF_F(0.055));  // unused when c <= thr
+            const float lo = clamp01(c * RPF_F(12.92));
+            out[k] = c <= RPF_F(0.0031308) ? lo : hi;
         }
         r[n] = out[0]; g[n] = out[1]; b[n] = out[2];
     }

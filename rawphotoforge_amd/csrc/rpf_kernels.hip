@@ -33,8 +33,28 @@ namespace rpf {
 
 // _SEQ (A/B only): the pair one pixel after the other.  _1: only the "main" mask exists (the common case): the
 // per-mask loops and the mask-plane reads are compiled out, which also frees the scalar registers they pin.
-// _1H: _1 whose hue curve is the identity as well (edit_chain's HUE_DIRECT).
-enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2, MODE_DEVELOP_1 = 3, MODE_DEVELOP_1H = 4 };
+// _1H: _1 whose hue curve is the identity as well (edit_chain's HUE_DIRECT).  _1P: _1H whose "main" is pristine
+// (MF_PRISTINE: every slider and curve at the reference default — a photo that was just opened; BASELINE's set D):
+// the flag word is a compile-time constant, so no stage tests, multiplies by or selects on a default.
+enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2, MODE_DEVELOP_1 = 3, MODE_DEVELOP_1H = 4,
+       MODE_DEVELOP_1P = 5 };
+constexpr bool mode_single(int mode) { return mode == MODE_DEVELOP_1 || mode == MODE_DEVELOP_1H || mode == MODE_DEVELOP_1P; }
+
+// The math tables as the kernels address them: by LDS byte address (rpf_math.h LdsPowTable).  `base` = LDS address of
+// the staged MathTables; the sin/cos tables (corner cases and non-identity hue curves only) stay an ordinary reference.
+struct LdsTabs {
+    LdsPowTable cbrt, gamma;
+    const SinCosTable& sc;
+    __device__ __forceinline__ LdsTabs(uint32_t base, const MathTables* T)
+        : cbrt{base + (uint32_t)offsetof(MathTables, cbrt)}, gamma{base + (uint32_t)offsetof(MathTables, gamma)}, sc(T->sc) {}
+};
+// The dynamic shared block must start at LDS address 0 for LdsTabs' constant addresses to be right (it does: these
+// kernels declare no static __shared__ variable).  One scalar compare per launch; a mismatch is a build error to be
+// seen, not computed through.
+__device__ __forceinline__ void assert_lds_base(const unsigned char* smem)
+{
+    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
+}
 enum { OUT_RGBA_F32_PLAIN = 3 };  // internal (A/B only): RGBA32F with ordinary stores
 
 // ---------------------------------------------------------------------------
@@ -131,7 +151,7 @@ template <int MODE, bool LDS_LUT, int OUTFMT, int VIGN = 1>
 __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s1)[2], const float (&e1)[2],
                                             const float (&d)[2], const float (&v2)[2], const float (&h2)[2], int cx,
                                             int cy_top, const RawParamsDev& raw, const DeviceEdit& ed,
-                                            const DevLuts<LDS_LUT>& luts, const MathTables& T, int gx, int ry_top,
+                                            const DevLuts<LDS_LUT>& luts, const LdsTabs& T, int gx, int ry_top,
                                             const TileGeom& g, bool col_live, void* out, const float* cam,
                                             float vcx2 = 0.0f, float vcy2_top = 0.0f, float vcy2_bot = 0.0f)
 {
@@ -171,9 +191,11 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
             }
         }
         uint32_t active[2] = {1u, 1u};
-        if (MODE != MODE_DEVELOP_1 && MODE != MODE_DEVELOP_1H && ed.num_masks > 1)
+        if (!mode_single(MODE) && ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(ed, pix[k], (size_t)rows * W);
-        if (MODE == MODE_DEVELOP_1H) {
+        if (MODE == MODE_DEVELOP_1P) {
+            edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, ed.mp, 1u, luts, T);
+        } else if (MODE == MODE_DEVELOP_1H) {
             edit_chain<2, true>(r, gg, b, active, ed.mp, 1u, luts, T);
         } else if (MODE == MODE_DEVELOP_1) {
             edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
@@ -241,10 +263,12 @@ void k_stream(const StreamArgs a)
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
     const int tid = threadIdx.x;
     if (MODE != MODE_DEMOSAIC) {
+        assert_lds_base(smem);
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
+    const LdsTabs tabs(0u, T);
 
     const int lane = tid & 63;
     const int W = (int)a.g.width, H = (int)a.g.height;
@@ -373,7 +397,7 @@ void k_stream(const StreamArgs a)
                 vcy2_top = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p));
                 vcy2_bot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p + 1));
             }
-            finish_pair<MODE, LDS_LUT, OUTFMT, VIGN ? 2 : 0>(c, s1, e1, d, vv, h2, cx, bp, a.raw, a.ed, luts, *T, xl,
+            finish_pair<MODE, LDS_LUT, OUTFMT, VIGN ? 2 : 0>(c, s1, e1, d, vv, h2, cx, bp, a.raw, a.ed, luts, tabs, xl,
                                                              2 * (pair0 + p), a.g, col_live, a.out, camv, vcx2, vcy2_top,
                                                              vcy2_bot);
             // slide the window down two rows
@@ -411,7 +435,11 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
     const int tid = threadIdx.x;
     const int W = (int)a.g.width, H = (int)a.g.height;
     const int y0 = (int)a.g.y0, rows = (int)a.g.rows;
-    if (MODE == MODE_DEVELOP) stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+    if (MODE == MODE_DEVELOP) {
+        assert_lds_base(smem);
+        stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+    }
+    const LdsTabs tabs((uint32_t)((TILE_ELEMS * 4 + 15) & ~15), T);
     const int lx = tid & (TILE_W - 1);
     const int ly = 2 * (tid / TILE_W);
     const int lane = tid & 63;
@@ -456,7 +484,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
         const float d[2] = {p1[1] + p1[3], p1[2] + p1[4]};
         const float vv[2] = {v[0] + v[4], v[1] + v[5]};
         const float h2[2] = {p2[2], p2[3]};
-        finish_pair<MODE, LDS_LUT, OUTFMT>(c, s1, e1, d, vv, h2, cx, cy_top, a.raw, a.ed, luts, *T, gx, ty0 + ly, a.g,
+        finish_pair<MODE, LDS_LUT, OUTFMT>(c, s1, e1, d, vv, h2, cx, cy_top, a.raw, a.ed, luts, tabs, gx, ty0 + ly, a.g,
                                            gx < W, a.out, a.raw.cam);
     }
 }
@@ -488,9 +516,11 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     MathTables* T = reinterpret_cast<MathTables*>(smem);
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
     const int tid = threadIdx.x;
+    assert_lds_base(smem);
     stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
+    const LdsTabs tabs(0u, T);
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
     const uint32_t stride = gridDim.x * NT * 2;
@@ -546,9 +576,9 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         if (!SINGLE && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
         if (SINGLE == 2)
-            edit_chain<2, true>(r, g, b, active, a.ed.mp, 1u, luts, *T);
+            edit_chain<2, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else
-            edit_chain<2>(r, g, b, active, a.ed.mp, SINGLE ? 1u : a.ed.num_masks, luts, *T);
+            edit_chain<2>(r, g, b, active, a.ed.mp, SINGLE ? 1u : a.ed.num_masks, luts, tabs);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (live[k]) store_px<OUTFMT>(a.out, pix[k], r[k], g[k], b[k]);
@@ -832,6 +862,8 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     if (OUTFMT == OUT_RGBA_F32 && !lut && cfg.variant == 3)  // A/B: the pixel pair one after the other
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
     if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
+        if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // variant 12 (A/B): run-time flags also for a pristine "main"
+            return run_stream<256, MODE_DEVELOP_1P, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
         if ((ed.mp[0].flags & MF_HUE_IDENTITY) && cfg.variant != 11)  // variant 11 (A/B): sincos_hue also for an identity hue curve
             return lut ? run_stream<1024, MODE_DEVELOP_1H, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                        : run_stream<256, MODE_DEVELOP_1H, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
@@ -849,6 +881,8 @@ static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_pack
     const uint16_t* in = reinterpret_cast<const uint16_t*>(d_packed);
     const bool lut = needs_lds_lut(ed);
     if (ed.num_masks == 1) {
+        if (ed.mp[0].flags == MF_PRISTINE)
+            return run_stream<256, MODE_DEVELOP_1P, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
         if (ed.mp[0].flags & MF_HUE_IDENTITY)
             return lut ? run_stream<1024, MODE_DEVELOP_1H, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                        : run_stream<256, MODE_DEVELOP_1H, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);

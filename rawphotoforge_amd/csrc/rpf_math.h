@@ -12,6 +12,7 @@
 // be checked exhaustively against the oracle (tests/test_math_exhaustive.py).
 // Everything here is branch-free (selects only): no divergence, no calls.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -86,14 +87,16 @@ RPF_HD uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 RPF_HD float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 RPF_HD double hilo2d(uint32_t hi, uint32_t lo) { return u2d(((uint64_t)hi << 32) | lo); }
 
-// f32(k) / d for integer k in [0, 65535] and d in {65535, 32767.5}: q = k*r, one
-// fma residual, one fma correction.  Equal to the IEEE quotient for every k
-// (checked exhaustively in tests/test_math_exhaustive.py).  wgsl:303-305, 328-330.
+// f32(k) / d for integer k in [0, 65535] and d in {65535, 32767.5}: the reciprocal as an unevaluated sum of two
+// binary32 values (1/65535 = 2^-16 (1 + 2^-16) + 2^-48 (1 + 2^-16) + ..., 1/32767.5 twice that), one product and
+// one fma: RN(k rd_hi + RN(k rd_lo)).  Equal to the IEEE quotient for every k (checked exhaustively in
+// tests/test_math_exhaustive.py; round 1 used Markstein's three-operation sequence).  wgsl:303-305, 328-330.
+// `rd` is RN(1/d) as before (= rd_hi); rd_lo follows from it because both constants share the pattern above.
 RPF_HD float div_u16f_by(float kf, float d, float rd)  // kf: an integer in [0, 65535] held as binary32
 {
-    const float q0 = kf * rd;
-    const float e = __builtin_fmaf(-q0, d, kf);
-    return __builtin_fmaf(e, rd, q0);
+    (void)d;
+    const float rd_lo = rd * 0x1p-32f;  // exact scaling, folded at compile time (rd is a literal at every call site)
+    return __builtin_fmaf(kf, rd, kf * rd_lo);
 }
 RPF_HD float div_u16_by(uint32_t k, float d, float rd) { return div_u16f_by((float)k, d, rd); }
 
@@ -121,6 +124,37 @@ RPF_HD float div_by_const(float x, float d, float rd)
 // with no select; a SUBNORMAL x also returns 0.  The chain cannot produce one where it matters: cube-root
 // inputs are 0 or >= 7e-7 (M1 times channels that are multiples of 1/65535), and below 0.0031308 the gamma
 // stage takes its linear branch.
+// The two table reads of powc_d, by byte offset.  A PowTable in ordinary memory (host, global) ...
+RPF_HD void pow_table_read(const PowTable& T, uint32_t eoff, uint32_t joff, double& e2, double& tj, double& r)
+{
+    const double* tr = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.TR[0][0]) + joff);
+    e2 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.E[0]) + eoff);
+    tj = tr[0]; r = tr[1];
+}
+#if defined(__HIPCC__)
+// ... or one staged in LDS, named by its LDS BYTE ADDRESS.  The kernels' only shared memory is the dynamic block, which
+// therefore starts at LDS address 0 (asserted once per launch, k_stream / k_apply); with the address a compile-time
+// constant plus the offset the read is `ds_read_b128 v, v_off offset:const` — through a pointer derived from the
+// `extern __shared__` symbol the compiler adds the (zero) base to every offset first: 12 extra VALU per pixel.
+struct LdsPowTable {
+    uint32_t base;
+};
+typedef const __attribute__((address_space(3))) double* lds_cdouble_ptr;
+typedef double lds_double2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) lds_double2* lds_cdouble2_ptr;
+__device__ __forceinline__ void pow_table_read(const LdsPowTable& T, uint32_t eoff, uint32_t joff, double& e2, double& tj,
+                                               double& r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    e2 = *(lds_cdouble_ptr)(T.base + (uint32_t)offsetof(PowTable, E) + eoff);
+    const lds_double2 tr = *(lds_cdouble2_ptr)(T.base + (uint32_t)offsetof(PowTable, TR) + joff);
+    tj = tr.x; r = tr.y;
+#else
+    (void)T; (void)eoff; (void)joff; e2 = tj = r = 0.0;  // host pass of the HIP compilation: never called
+#endif
+}
+#endif
+
 template <int KIND, class TabT>
 RPF_HD double powc_d(float x, const TabT& T)  // the binary64 value before the single rounding
 {
@@ -128,9 +162,8 @@ RPF_HD double powc_d(float x, const TabT& T)  // the binary64 value before the s
     const uint32_t eoff = (b >> 20) & 0x7f8u;  // biased exponent * 8: byte offset into E
     const uint32_t joff = (b >> (19 - RPF_POW_BITS)) & (((1u << RPF_POW_BITS) - 1u) << 4);  // top 9 mantissa bits * 16: byte offset into TR
     const double m = (double)bits2f((b & 0x007fffffu) | 0x3f800000u);  // significand in [1, 2), exact
-    const double* tr = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.TR[0][0]) + joff);
-    const double e2 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T.E[0]) + eoff);
-    const double tj = tr[0], r = tr[1];
+    double e2, tj, r;
+    pow_table_read(T, eoff, joff, e2, tj, r);
     const double t = __builtin_fma(m, r, -1.0);
     using K = PowCoef<KIND>;
 #if RPF_POW_BITS >= 9
@@ -255,23 +288,21 @@ template <class Entry>
 RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out, bool& passed_out, uint32_t& zero_negx_out)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    // q = min / max in [0, 1] feeds the approximation only (its error budget is 0.38 index units, a hardware
+    // reciprocal's 1 ulp is nothing).  The larger magnitude is clamped into [2^-100, 2^100] first: the floor keeps
+    // a = b = 0 at q = 0 instead of 0 * inf, the ceiling keeps the reciprocal a normal number — outside that range
+    // (which the chain cannot reach: |a|, |b| < 8, and a nonzero one is > 2^-75) the candidate may be off and the
+    // function is not specified.  Straight-line code on purpose: written as a select around the table read, the
+    // compiler turns it into a branch per pixel with the gather and its wait inside, which serialises the pair
+    // and exposes the whole L2 latency.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float q = mn * __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(mx, 0x1p-100f, 0x1p+100f));
+#else
     const float mx = ax > ay ? ax : ay;
     const float mn = ax > ay ? ay : ax;
-    // scale so that mx lands in [1, 2): the reciprocal below neither overflows nor meets a denormal
-    uint32_t eb = f2bits(mx) >> 23;
-    eb = eb > 253u ? 253u : eb;
-    const float sc = bits2f((254u - eb) << 23);
-    // mx == 0 (a = b = 0): the floor keeps the quotient at 0 instead of 0 * inf — straight-line code on purpose:
-    // written as a select around the table read, the compiler turns it into a branch per pixel with the
-    // gather and its wait inside, which serialises the pair and exposes the whole L2 latency
-    const float mns = mn * sc;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float mxs = __builtin_fmaxf(mx * sc, 0x1p-100f);
-    const float q = mns * __builtin_amdgcn_rcpf(mxs);
-#else
-    const float mxs0 = mx * sc;
-    const float mxs = mxs0 > 0x1p-100f ? mxs0 : 0x1p-100f;
-    const float q = mns / mxs;
+    const float mxc = mx < 0x1p-100f ? 0x1p-100f : (mx > 0x1p+100f ? 0x1p+100f : mx);
+    const float q = mn / mxc;
 #endif
     // atan(q) * 65535 / (2 pi) for q in [0, 1], |error| < 0.12 index units (tools/gen_math_consts.py)
     const float z = q * q;
@@ -283,7 +314,8 @@ RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out,
     v = ay > ax ? 16383.75f - v : v;   // pi/2 - a
     v = x < 0.0f ? 32767.5f - v : v;   // pi - a
     v = y < 0.0f ? 65535.0f - v : v;   // 2 pi - a (the wrap of wgsl:73); y = -0 counts as +0, like atan2's -0 result
-    const uint32_t j = (uint32_t)(v + 0.5f) & 0xffffu;
+    // nearest integer of v in [0, 65535.x] without a conversion (half-rate on gfx950): the low bits of v + 2^23
+    const uint32_t j = f2bits(v + 8388608.0f) & 0xffffu;
     const Entry bd = hb[j];
     const double d = __builtin_fma((double)y, bd.c, -((double)x * bd.s));
     const bool passed = d >= 0.0;
@@ -319,6 +351,27 @@ RPF_HD uint32_t hue_index_cs(float y, float x, const HueBoundCs* hb, const TabT&
     sn = passed ? bd.cs_k[1] : bd.cs_km1[1];
     if (__builtin_expect(zn != 0u, 0)) sincos_hue(k, S, cs, sn);
     return k;
+}
+
+// Correctly rounded binary32 square root (wgsl:70 `sqrt`, wgsl:170 `length`).  The compiler's IEEE expansion of
+// sqrtf costs 16 instructions on gfx950 (scaling for subnormal inputs, v_sqrt_f32, two trial residuals, four selects).
+// For s in [2^-96, 2^96) none of the scaling is needed and one Markstein step does it: y0 = s g with g = v_rsq_f32(s)
+// (1 ulp), the residual r = s - y0^2 is exact in one fma, y = y0 + r (g / 2) rounds once.  Pre-rounding error ~2^-44
+// relative; that this always rounds like the IEEE sqrt is checked on EVERY binary32 of the range on the GPU
+// (tests/test_gpu_math.py).  Zero, subnormal-range, huge, inf and NaN inputs take the IEEE sequence (a rarely taken,
+// wave-uniformly skipped branch).  The host build is sqrtf, which is what the device result equals.
+RPF_HD float sqrt_cr(float s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one unsigned compare on the bit pattern: negative, NaN, inf, zero and everything outside [2^-96, 2^96) fail it
+    if (__builtin_expect(f2bits(s) - 0x0f800000u >= 0x60000000u, 0)) return __builtin_sqrtf(s);
+    const float g = __builtin_amdgcn_rsqf(s);
+    const float y0 = s * g;
+    const float r = __builtin_fmaf(-y0, y0, s);
+    return __builtin_fmaf(r, 0.5f * g, y0);
+#else
+    return __builtin_sqrtf(s);
+#endif
 }
 
 // pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171): x * sqrt(x) in binary64 is within

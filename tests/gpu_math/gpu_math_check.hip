@@ -1,0 +1,48 @@
+// gpu_math_check.hip — TEST INFRASTRUCTURE ONLY: runs device functions of rpf_math.h that have no bit-identical host
+// twin (they use gfx950's approximate v_rsq_f32 / v_rcp_f32) over whole ranges of binary32 inputs ON THE GPU and counts
+// the results that differ from the reference expression.  Built and loaded by tests/test_gpu_math.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../rawphotoforge_amd/csrc/rpf_math.h"
+
+// sqrt_cr(s) against the compiler's IEEE expansion of sqrtf for the bit patterns [lo, lo + n)
+__global__ void k_check_sqrt(uint32_t lo, uint64_t n, unsigned long long* bad, uint32_t* first_bad)
+{
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float s = rpf::bits2f(lo + (uint32_t)i);
+        const float got = rpf::sqrt_cr(s);
+        float ref;
+        {
+            volatile float sv = s;  // keep the reference on the plain sqrtf path
+            ref = __builtin_sqrtf(sv);
+        }
+        const bool same = rpf::f2bits(got) == rpf::f2bits(ref) || (got != got && ref != ref);
+        if (!same) {
+            ++mine;
+            atomicMin(first_bad, lo + (uint32_t)i);
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+extern "C" int gpu_check_sqrt(uint32_t lo_bits, uint64_t n, uint64_t* mismatches, uint32_t* first_bad_bits)
+{
+    unsigned long long* d_bad = nullptr;
+    uint32_t* d_first = nullptr;
+    if (hipMalloc((void**)&d_bad, sizeof(*d_bad)) != hipSuccess) return 1;
+    if (hipMalloc((void**)&d_first, sizeof(*d_first)) != hipSuccess) return 1;
+    const uint32_t ff = 0xffffffffu;
+    (void)hipMemset(d_bad, 0, sizeof(*d_bad));
+    (void)hipMemcpy(d_first, &ff, sizeof(ff), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_check_sqrt, dim3(256 * 8), dim3(256), 0, 0, lo_bits, n, d_bad, d_first);
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    unsigned long long bad = 0;
+    (void)hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(first_bad_bits, d_first, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    (void)hipFree(d_first);
+    *mismatches = bad;
+    return 0;
+}

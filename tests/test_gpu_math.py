@@ -1,0 +1,37 @@
+"""Device functions of rpf_math.h without a bit-identical host twin (they start from gfx950's approximate
+v_rsq_f32), checked ON THE GPU over whole ranges of binary32 inputs (run on the GPU box: -m gpu)."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "gpu_math", "gpu_math_check.hip")
+LIB = os.path.join(HERE, "gpu_math", "librpf_gpu_math_check.so")
+HDR = os.path.join(HERE, "..", "rawphotoforge_amd", "csrc", "rpf_math.h")
+
+
+@pytest.fixture(scope="module")
+def checker():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--offload-arch=gfx950", "-O3",
+                        "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", SRC, "-o", LIB], check=True)
+    lib = C.CDLL(LIB)
+    lib.gpu_check_sqrt.restype = C.c_int
+    lib.gpu_check_sqrt.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    return lib
+
+
+def test_sqrt_cr_equals_ieee_sqrt_on_every_binary32(checker):
+    """sqrt_cr = one Markstein step on v_rsq_f32 inside [2^-96, 2^96), the IEEE sequence elsewhere: every one of
+    the 2^32 bit patterns (negative, NaN, inf, zeros, subnormals included) must give the bits of sqrtf."""
+    total = 0
+    for lo in range(0, 1 << 32, 1 << 30):
+        bad, first = C.c_uint64(0), C.c_uint32(0)
+        assert checker.gpu_check_sqrt(lo, 1 << 30, C.byref(bad), C.byref(first)) == 0
+        assert bad.value == 0, f"{bad.value} mismatches in [{lo:#x}, +2^30), first at bits {first.value:#010x}"
+        total += 1 << 30
+    assert total == 1 << 32

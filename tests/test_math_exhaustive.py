@@ -200,7 +200,10 @@ def test_hue_index_special_arguments():
     z, nz = 0.0, -0.0
     cases = [(z, z), (nz, z), (z, nz), (nz, nz), (z, 1), (nz, 1), (z, -1), (nz, -1), (1, z), (1, nz), (-1, z), (-1, nz),
              (1e-30, 1), (-1e-30, 1), (1e-30, -1), (-1e-30, -1), (1, 1e-30), (1, -1e-30), (1, 1), (-1, 1), (1, -1), (-1, -1),
-             (3e-39, 1e-39), (-3e-39, 1e-39), (1e-39, -3e-39), (1e38, 1e38), (-1e38, 3e38), (1e-45, 1e-45), (-1e-45, -1e-45),
+             # the larger magnitude anywhere in the supported [2^-100, 2^100] (rpf_math.h hue_index_core; the chain's
+             # |a|, |b| lie in {0} + [2^-75, 8)); the smaller one may be anything, subnormals included
+             (3e-30, 1e-30), (-3e-30, 1e-30), (1e-30, -3e-30), (1e30, 1e30), (-1e29, 3e29), (8e-31, 8e-31), (-8e-31, -8e-31),
+             (1e-45, 1e-30), (-1e-45, -1e30), (1e-39, 1.0), (1.0, -1e-42),
              (-1e-7, 1), (-1.9e-7, 1), (-2e-7, 1), (6e-8, -1), (-6e-8, -1)]
     y, x = np.float32([c[0] for c in cases]), np.float32([c[1] for c in cases])
     a, b = _hue_both(y, x)
