@@ -121,6 +121,39 @@ __device__ __forceinline__ void store_px(void* out, size_t pix, float r, float g
     }
 }
 
+// gfx9 raw buffer descriptor, dword 3 (DATA_FORMAT = 32-bit): offsets past num_records are dropped / read as 0
+constexpr int RPF_BUFFER_RSRC_FLAGS = 0x00020000;
+
+// The pixel at column `col` of the output row whose first pixel is `row_pix` (wave-uniform), through a buffer
+// descriptor of THAT ROW built in scalar registers (base = the row's address, num_records = the row's bytes): the
+// lane contributes a 32-bit byte offset and nothing else — `buffer_store_dwordx4 v_data, v_off, s[rsrc], 0 offen nt`,
+// no 64-bit vector address arithmetic (through store_px the compiler spends a v_mad_i64_i32 and a v_lshl_add_u64,
+// both half-rate, on every pixel) — and a lane whose column lies beyond the row (a ragged last strip) is dropped by
+// the hardware's range check instead of by an exec-mask dance around the store.
+template <int OUTFMT>
+__device__ __forceinline__ void store_px_row(void* out, size_t row_pix, uint32_t width, uint32_t col, float r, float g, float b)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+    constexpr uint32_t BPP = (OUTFMT == OUT_RGBA_F32 || OUTFMT == OUT_RGBA_F32_PLAIN) ? 16u : (OUTFMT == OUT_RGB_F32 ? 12u : 3u);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(out) + row_pix * BPP, 0, (int)(width * BPP), RPF_BUFFER_RSRC_FLAGS);
+    const uint32_t off = col * BPP;
+    if (OUTFMT == OUT_RGBA_F32) {
+        // nontemporal (aux bit 1): the frame is written once and never re-read by the kernel; measured on MI355X the
+        // demosaic kernel goes from 4.2 to 5.7 TB/s with it (profiles/r01_experiments.md)
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{f2bits(r), f2bits(g), f2bits(b), 0x3f800000u}, rs, off, 0, 2);
+    } else if (OUTFMT == OUT_RGBA_F32_PLAIN) {
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{f2bits(r), f2bits(g), f2bits(b), 0x3f800000u}, rs, off, 0, 0);
+    } else if (OUTFMT == OUT_RGB_F32) {  // image.rs:202-277
+        __builtin_amdgcn_raw_buffer_store_b96(v3u{f2bits(r), f2bits(g), f2bits(b)}, rs, off, 0, 0);
+    } else {  // image.rs:375-383: (v.clamp(0,1) * 255.0) as u8
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(clamp01(r) * 255.0f), rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(clamp01(g) * 255.0f), rs, off + 1u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(clamp01(b) * 255.0f), rs, off + 2u, 0, 0);
+    }
+}
+
 __device__ __forceinline__ uint32_t active_masks(const DeviceEdit& ed, size_t pix, size_t plane)
 {
     uint32_t active = 1u;  // "main" is all ones by construction (lib.rs:193-196)
@@ -176,10 +209,10 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
 
     const int W = (int)g.width, rows = (int)g.rows;
     bool live[2];
-    size_t pix[2];
+    size_t pix[2] = {0, 0};
     for (int k = 0; k < 2; ++k) {
         live[k] = col_live && ry_top + k < rows;
-        pix[k] = live[k] ? (size_t)(ry_top + k) * W + gx : 0;
+        if (!mode_single(MODE)) pix[k] = live[k] ? (size_t)(ry_top + k) * W + gx : 0;  // mask-plane index
     }
     if (MODE != MODE_DEMOSAIC) {
         if (VIGN == 2 || (VIGN == 1 && ed.vign_strength != 0.0f)) {  // wgsl:166-178, global coordinates
@@ -210,8 +243,10 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
             edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
         }
     }
+    // rows past a ragged band: a wave-uniform test; columns past a ragged strip: the row descriptor's range check
     for (int k = 0; k < 2; ++k)
-        if (live[k]) store_px<OUTFMT>(out, pix[k], r[k], gg[k], b[k]);
+        if (ry_top + k < rows)
+            store_px_row<OUTFMT>(out, (size_t)(ry_top + k) * (size_t)W, (uint32_t)W, (uint32_t)gx, r[k], gg[k], b[k]);
 }
 
 // ---------------------------------------------------------------------------
@@ -255,7 +290,7 @@ typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // one global_load_
 
 // 256-thread builds are launched five workgroups per CU: tell the register allocator (<= 96 VGPRs)
 template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool PACKED = false, bool VIGN = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 5 : 1)))
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 5 : (NT == 512 ? 6 : 1))))
 void k_stream(const StreamArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -269,6 +304,9 @@ void k_stream(const StreamArgs a)
     }
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
     const LdsTabs tabs(0u, T);
+    // the u16 band as one buffer: (rows + 4) rows of W samples (run_stream checks that it is shorter than 4 GiB)
+    const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
 
     const int lane = tid & 63;
     const int W = (int)a.g.width, H = (int)a.g.height;
@@ -320,6 +358,7 @@ void k_stream(const StreamArgs a)
         int hx = lane < 2 ? xl - 2 : (lane >= 62 ? xl + 2 : xl);
         hx = reflect101(hx, W);
         hx = hx < 0 ? 0 : (hx > W - 1 ? W - 1 : hx);
+        const uint32_t goff = (uint32_t)gx * 2u, hoff = (uint32_t)hx * 2u;  // byte offsets inside a u16 row
         // Row addressing: lane j works out, once per item, the element offset of window row j of this
         // item (reflect-101 at the frame edge, clamp inside the band buffer); the loop then fetches the two
         // offsets it needs per step with v_readlane instead of redoing ~20 scalar operations per row on
@@ -330,7 +369,7 @@ void k_stream(const StreamArgs a)
             int gy = reflect101(y0 + rbase + lane, H);
             int br = gy - (y0 - 2);
             br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);  // rows past a ragged band: unused
-            rowoff = (uint32_t)br * (PACKED ? a.row_stride : (uint32_t)W);  // bytes (packed) or elements
+            rowoff = (uint32_t)br * (PACKED ? a.row_stride : (uint32_t)W * 2u);  // bytes
         }
         // PACKED: the integer unpack of rpf_dev_unpack_bayer folded into the row loads.  A lane's column fixes the
         // byte address and the shift of its sample inside a 32-bit big-endian window once per item; the window is
@@ -357,7 +396,9 @@ void k_stream(const StreamArgs a)
                 const uint32_t w = a.lsb ? raw32 : __builtin_bswap32(raw32);
                 return (w >> (halo ? cshift_h : cshift_g)) & smask;
             }
-            return (a.cfa + ro)[halo ? hx : gx];
+            // one descriptor of the whole band, the row's byte offset in a scalar register, the lane's column as a
+            // 32-bit byte offset: `buffer_load_ushort v, v_off, s[rsrc], s_row offen` — no 64-bit vector address
+            return __builtin_amdgcn_raw_buffer_load_b16(band_rsrc, halo ? hoff : goff, ro, 0);
         };
         // Vignette (wgsl:166-178): the column's squared coordinate once per item; lane j holds the squared
         // coordinate of the item's output row j (two IEEE divisions per lane per item instead of two per pixel)
@@ -366,8 +407,9 @@ void k_stream(const StreamArgs a)
             vcx2 = vignette_axis2(xl, (float)W);
             vcy2_lane = vignette_axis2(y0 + 2 * pair0 + lane, (float)H);
         }
-        auto normE = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkE, 0.0f), rngE) * sclE; };
-        auto normO = [&](uint32_t raw) { return fminf(fmaxf((float)raw - blkO, 0.0f), rngO) * sclO; };
+        // clamp(v, 0, range) as one v_med3_f32 (v is finite, range > 0: the same value as min(max(v, 0), range))
+        auto normE = [&](uint32_t raw) { return __builtin_amdgcn_fmed3f((float)raw - blkE, 0.0f, rngE) * sclE; };
+        auto normO = [&](uint32_t raw) { return __builtin_amdgcn_fmed3f((float)raw - blkO, 0.0f, rngO) * sclO; };
 
         // window position i <-> band row 2*pair - 2 + i
         const float v0 = normE(sample(0, false));
@@ -733,6 +775,9 @@ static hipError_t check_geom(const TileGeom& g, bool bayer)
     if ((uint64_t)g.y0 + g.rows > g.height) return hipErrorInvalidValue;
     if (bayer && (g.width < 3 || g.height < 3)) return hipErrorInvalidValue;
     if ((uint64_t)g.width * g.rows > (1ull << 31)) return hipErrorInvalidValue;
+    // the fused kernels address the (rows + 4)-row u16 band and one output row through 32-bit buffer offsets
+    if (bayer && (uint64_t)g.width * ((uint64_t)g.rows + 4) * 2 >= (1ull << 32)) return hipErrorInvalidValue;
+    if ((uint64_t)g.width * 16 >= (1ull << 32)) return hipErrorInvalidValue;
     return hipSuccess;
 }
 
@@ -772,7 +817,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     // persistent workgroups for the fused kernel (LDS tables staged once per workgroup), as many as are resident: it
     // needs < 96 VGPRs, i.e. 5 waves per SIMD (variant 6: 4, for A/B); the 128-KiB curve in LDS limits that variant
     // to one 1024-thread workgroup per CU
-    uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
+    uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : (NT == 512 ? 1536 : 1280)) / NT);
     if (MODE != MODE_DEMOSAIC) {  // never more than are resident (a register count over 96 would halve the last round)
         // per build (without / with the vignette stage); atomic: two host threads may launch for the first time
         // together (both then store the same value)
@@ -862,6 +907,8 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     if (OUTFMT == OUT_RGBA_F32 && !lut && cfg.variant == 3)  // A/B: the pixel pair one after the other
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
     if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
+        if (ed.mp[0].flags == MF_PRISTINE && cfg.variant == 13)  // A/B: three 512-thread workgroups per CU (6 waves per SIMD)
+            return run_stream<512, MODE_DEVELOP_1P, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
         if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // variant 12 (A/B): run-time flags also for a pristine "main"
             return run_stream<256, MODE_DEVELOP_1P, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
         if ((ed.mp[0].flags & MF_HUE_IDENTITY) && cfg.variant != 11)  // variant 11 (A/B): sincos_hue also for an identity hue curve

@@ -283,8 +283,10 @@ struct HueBoundCs {
     float cs_km1[2];
 };
 
-// `bd_out` / `passed_out`: the table entry that was read and the side of its boundary (for hue_index_cs)
-template <class Entry>
+// `bd_out` / `passed_out`: the table entry that was read and the side of its boundary (for hue_index_cs).
+// NEG_ZERO_X = false: the caller's promise that x is never -0 while y is +-0 (then atan2 = +-pi, index 32767, is the
+// one result no boundary decides); it saves the two compares and the merge that exist for that argument alone.
+template <bool NEG_ZERO_X = true, class Entry>
 RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out, bool& passed_out, uint32_t& zero_negx_out)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
@@ -296,7 +298,11 @@ RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out,
     // compiler turns it into a branch per pixel with the gather and its wait inside, which serialises the pair
     // and exposes the whole L2 latency.
 #if defined(__HIP_DEVICE_COMPILE__)
-    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    // one v_max_f32 / v_min_f32 each with |.| source modifiers (through fmaxf / fminf the compiler first
+    // "canonicalises" both magnitudes with a v_max of their own: four half-rate instructions instead of two)
+    float mx, mn;
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
+    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
     const float q = mn * __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(mx, 0x1p-100f, 0x1p+100f));
 #else
     const float mx = ax > ay ? ax : ay;
@@ -324,32 +330,33 @@ RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out,
     passed_out = passed;
     // a = b = 0 arrives here as j = 0, d = +-0, k = 0, which is atan2(+-0, +0) = +-0 -> 0;
     // atan2(+-0, -0) = +-pi -> 32767 is OR-ed in (k is 0 in that case)
-    const uint32_t zero_negx = (mx == 0.0f) ? ((f2bits(x) >> 31) * 32767u) : 0u;
+    const uint32_t zero_negx = (NEG_ZERO_X && mx == 0.0f) ? ((f2bits(x) >> 31) * 32767u) : 0u;
     zero_negx_out = zero_negx;
     return k | zero_negx;
 }
 
+template <bool NEG_ZERO_X = true>
 RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
 {
     HueBound bd;
     bool passed;
     uint32_t zn;
-    return hue_index_core(y, x, hb, bd, passed, zn);
+    return hue_index_core<NEG_ZERO_X>(y, x, hb, bd, passed, zn);
 }
 
 // The index together with cos / sin of ITS hue angle (= sincos_hue(k)), read from the same table entry: for
 // launches whose hue curve is the identity the whole of sincos_hue (four LDS reads, eleven binary64 operations)
 // falls away.  The a = b = 0, a = -0 corner (k = 32767, not a neighbour of the entry read) takes the slow path.
-template <class TabT>
+template <bool NEG_ZERO_X = true, class TabT>
 RPF_HD uint32_t hue_index_cs(float y, float x, const HueBoundCs* hb, const TabT& S, float& cs, float& sn)
 {
     HueBoundCs bd;
     bool passed;
     uint32_t zn;
-    const uint32_t k = hue_index_core(y, x, hb, bd, passed, zn);
+    const uint32_t k = hue_index_core<NEG_ZERO_X>(y, x, hb, bd, passed, zn);
     cs = passed ? bd.cs_k[0] : bd.cs_km1[0];
     sn = passed ? bd.cs_k[1] : bd.cs_km1[1];
-    if (__builtin_expect(zn != 0u, 0)) sincos_hue(k, S, cs, sn);
+    if (NEG_ZERO_X && __builtin_expect(zn != 0u, 0)) sincos_hue(k, S, cs, sn);
     return k;
 }
 
