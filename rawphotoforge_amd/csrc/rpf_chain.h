@@ -191,18 +191,6 @@ RPF_HD float clamp01(float v)
 #endif
 }
 
-// A constant that feeds an f32 operation carrying the clamp output modifier.  Such an operation needs the VOP3
-// encoding, which on gfx9 cannot hold a 32-bit literal: the compiler parks the constant in a scalar register, and an
-// f32 operation with an SGPR operand issues at half rate on gfx950 (tools/microbench.hip: 1.73 vs 1.09 ns).  The empty
-// asm pins it in a vector register instead (loop-invariant, so it is materialised once per kernel).
-RPF_HD float vgpr_const(float c)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(c));
-#endif
-    return c;
-}
-
 RPF_HD float max0(float v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -349,7 +337,7 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         for (int n = 0; n < N; ++n) {
             const uint32_t hu = main_mask ? hu0[n] : (uint32_t)(h[n] * 65535.0f);
             uint32_t nh = hu;
-            float sat_gain = vgpr_const(P.sat_gain), light_gain = vgpr_const(P.light_gain);  // uniforms: see vgpr_const
+            float sat_gain = P.sat_gain, light_gain = P.light_gain;
             if (!trivial) luts.hsl(m, hu, P, nh, sat_gain, light_gain);
             const bool on = main_mask ? true : (bool)((active[n] >> m) & 1u);
             hue_k[n] = on ? nh : hue_k[n];
@@ -364,7 +352,6 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
 
     // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336).  The hue reaching
     // here is always k/65535 for the integer k the last active mask fetched ("main" is always active).
-    const float k_0055 = vgpr_const(RPF_F(0.055)), k_1292 = vgpr_const(RPF_F(12.92));
     for (int n = 0; n < N; ++n) {
         float cs = cs0[n], sn = sn0[n];
         if (!HUE_DIRECT) sincos_hue(hue_k[n], T.sc, cs, sn);
@@ -381,8 +368,8 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
             const float c = lin[k];
             // clamp(select(a, b)) == select(clamp(a), clamp(b)); written this way each clamp is the free output
             // modifier of the multiplication / addition in front of it instead of a v_max of its own
-            const float hi = clamp01(RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - k_0055);  // unused when c <= thr
-            const float lo = clamp01(c * k_1292);
+            const float hi = clamp01(RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - RPF_F(0.055));  // unused when c <= thr
+            const float lo = clamp01(c * RPF_F(12.92));
             out[k] = c <= RPF_F(0.0031308) ? lo : hi;
         }
         r[n] = out[0]; g[n] = out[1]; b[n] = out[2];
