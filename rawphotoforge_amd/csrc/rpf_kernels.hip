@@ -131,14 +131,14 @@ constexpr int RPF_BUFFER_RSRC_FLAGS = 0x00020000;
 // both half-rate, on every pixel) — and a lane whose column lies beyond the row (a ragged last strip) is dropped by
 // the hardware's range check instead of by an exec-mask dance around the store.
 template <int OUTFMT>
-__device__ __forceinline__ void store_px_row(void* out, size_t row_pix, uint32_t width, uint32_t col, float r, float g, float b)
+constexpr uint32_t out_bpp() { return (OUTFMT == OUT_RGBA_F32 || OUTFMT == OUT_RGBA_F32_PLAIN) ? 16u : (OUTFMT == OUT_RGB_F32 ? 12u : 3u); }
+
+// one pixel at byte offset `off` of the buffer `rs` (offsets at or past its num_records are dropped by the hardware)
+template <int OUTFMT>
+__device__ __forceinline__ void store_px_buf(__amdgpu_buffer_rsrc_t rs, uint32_t off, float r, float g, float b)
 {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-    constexpr uint32_t BPP = (OUTFMT == OUT_RGBA_F32 || OUTFMT == OUT_RGBA_F32_PLAIN) ? 16u : (OUTFMT == OUT_RGB_F32 ? 12u : 3u);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<unsigned char*>(out) + row_pix * BPP, 0, (int)(width * BPP), RPF_BUFFER_RSRC_FLAGS);
-    const uint32_t off = col * BPP;
     if (OUTFMT == OUT_RGBA_F32) {
         // nontemporal (aux bit 1): the frame is written once and never re-read by the kernel; measured on MI355X the
         // demosaic kernel goes from 4.2 to 5.7 TB/s with it (profiles/r01_experiments.md)
@@ -152,6 +152,15 @@ __device__ __forceinline__ void store_px_row(void* out, size_t row_pix, uint32_t
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(clamp01(g) * 255.0f), rs, off + 1u, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(clamp01(b) * 255.0f), rs, off + 2u, 0, 0);
     }
+}
+
+template <int OUTFMT>
+__device__ __forceinline__ void store_px_row(void* out, size_t row_pix, uint32_t width, uint32_t col, float r, float g, float b)
+{
+    constexpr uint32_t BPP = out_bpp<OUTFMT>();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(out) + row_pix * BPP, 0, (int)(width * BPP), RPF_BUFFER_RSRC_FLAGS);
+    store_px_buf<OUTFMT>(rs, col * BPP, r, g, b);
 }
 
 __device__ __forceinline__ uint32_t active_masks(const DeviceEdit& ed, size_t pix, size_t plane)
@@ -550,7 +559,8 @@ struct TexFetch {
     }
 };
 
-// SINGLE: 0 = any number of masks, 1 = only "main", 2 = only "main" with an identity hue curve (HUE_DIRECT)
+// SINGLE: 0 = any number of masks, 1 = only "main", 2 = only "main" with an identity hue curve (HUE_DIRECT),
+// 3 = only a pristine "main" (MF_PRISTINE known at compile time; sincos_hue as in 1)
 template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE>
 __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
 {
@@ -567,14 +577,22 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
     const uint32_t stride = gridDim.x * NT * 2;
     const bool coords = LENS || a.ed.vign_strength != 0.0f;  // only these two stages look at the pixel position
-    // the pair's input is fetched one iteration ahead (the chain that follows is ~800 instructions long)
-    float4 nxt[2];
+    // One iteration of a workgroup = 2 * NT consecutive pixels starting at `base` (wave-uniform).  Input and output
+    // of the iteration are addressed through buffer descriptors of exactly that span, built in scalar registers: a
+    // thread's byte offsets inside the span never change, and pixels past the end of the image fall outside the
+    // descriptor (loads return 0, stores are dropped) — no per-pixel 64-bit addresses, clamps or exec masks.
+    // The pair's input is fetched one iteration ahead (the chain that follows is ~600 instructions long).
+    // (only r, g, b are loaded: the register of an unused alpha gets reused by the allocator while the load is
+    // still in flight, which forces a wait for the prefetch at that point)
+    typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+    constexpr uint32_t BPP = out_bpp<OUTFMT>();
+    v3u nxt[2];
+    auto span = [&](uint32_t base) { return base >= npix ? 0u : (npix - base < 2u * NT ? npix - base : 2u * NT); };
     auto fetch = [&](uint32_t base) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float4*>(a.in) + base, 0, (int)(span(base) * 16u), RPF_BUFFER_RSRC_FLAGS);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const uint32_t p = base + (uint32_t)k * NT + tid;
-            nxt[k] = a.in[p < npix ? p : npix - 1];
-        }
+        for (int k = 0; k < 2; ++k) nxt[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, ((uint32_t)k * NT + tid) * 16u, 0, 0);
     };
     uint32_t base = blockIdx.x * NT * 2;
     if (!LENS && base < npix) fetch(base);
@@ -588,9 +606,9 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
             const uint32_t p = base + (uint32_t)k * NT + tid;
             live[k] = p < npix;
             pix[k] = live[k] ? p : npix - 1;
-            if (!LENS) { r[k] = nxt[k].x; g[k] = nxt[k].y; b[k] = nxt[k].z; }
+            if (!LENS) { r[k] = bits2f(nxt[k].x); g[k] = bits2f(nxt[k].y); b[k] = bits2f(nxt[k].z); }
         }
-        if (!LENS && base + stride < npix) fetch(base + stride);
+        if (!LENS) fetch(base + stride);  // past the end of the image the span is empty: zeros that nobody uses
         const bool decode = (a.ed.flags & EF_DECODE_INPUT) != 0;  // Godot-legacy :281-283: the stored image is sRGB-encoded
         auto decode_px = [&](int k) {
             const PowTable& D = a.ed.legacy->decode;
@@ -617,13 +635,16 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         }
         if (!SINGLE && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
-        if (SINGLE == 2)
+        if (SINGLE == 3)
+            edit_chain<2, false, (int)MF_PRISTINE>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+        else if (SINGLE == 2)
             edit_chain<2, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else
             edit_chain<2>(r, g, b, active, a.ed.mp, SINGLE ? 1u : a.ed.num_masks, luts, tabs);
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<unsigned char*>(a.out) + (size_t)base * BPP, 0, (int)(span(base) * BPP), RPF_BUFFER_RSRC_FLAGS);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (live[k]) store_px<OUTFMT>(a.out, pix[k], r[k], g[k], b[k]);
+        for (int k = 0; k < 2; ++k) store_px_buf<OUTFMT>(ors, ((uint32_t)k * NT + tid) * BPP, r[k], g[k], b[k]);
     }
 }
 
@@ -1014,6 +1035,7 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
         // (HUE_DIRECT, SINGLE == 2, is not used here: with this kernel's 16-B/px input stream the 32-byte table read
         // costs more than sincos_hue saves — D 0.234 -> 0.249 ms)
         if (lens) return lut ? run_apply<true, true, OUTFMT, 1>(cfg, a, s) : run_apply<false, true, OUTFMT, 1>(cfg, a, s);
+        if (a.ed.mp[0].flags == MF_PRISTINE && a.ed.flags == 0) return run_apply<false, false, OUTFMT, 3>(cfg, a, s);
         return lut ? run_apply<true, false, OUTFMT, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 1>(cfg, a, s);
     }
     if (lens) return lut ? run_apply<true, true, OUTFMT, 0>(cfg, a, s) : run_apply<false, true, OUTFMT, 0>(cfg, a, s);

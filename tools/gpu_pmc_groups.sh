@@ -16,7 +16,7 @@ import csv, glob, collections
 agg = collections.OrderedDict()
 for f in sorted(glob.glob("$OUT/g_*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "rpf" in r["Kernel_Name"] and "k_stream" in r["Kernel_Name"]:
+        if "rpf" in r["Kernel_Name"] and "${KERN:-k_stream}" in r["Kernel_Name"]:
             agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 it = 24e6 / 128
 with open("$OUT/summary.txt", "w") as o:
