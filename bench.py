@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 W, H = 6000, 4000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_PX = {"develop": 18, "demosaic": 18, "apply": 32,   # u16 in + RGBA32F out
+BYTES_PER_PX = {"develop": 18, "batch": 18, "demosaic": 18, "apply": 32,   # u16 in + RGBA32F out
                 "unpack": 3.5,                                  # 12-bit packed in (1.5 B) + u16 out
                 "develop_packed": 17.75}                        # 14-bit packed in (1.75 B) + RGBA32F out
 
@@ -39,7 +39,12 @@ def main():
                     help="untimed steps before the W warmup steps (same count on every rank): an idle MI355X needs "
                          "~50 launches (15 ms) to reach its steady clocks, and steady state is what a production "
                          "service sees (profiles/r01_experiments.md)")
-    ap.add_argument("--workload", default="develop", choices=["develop", "demosaic", "apply", "unpack", "develop_packed"])
+    ap.add_argument("--workload", default="develop",
+                    choices=["develop", "demosaic", "apply", "unpack", "develop_packed", "batch"],
+                    help="develop = BASELINE configs[2] (the headline); batch = configs[4]: a pool of --frames different "
+                         "6000x4000 frames per GPU, one whole frame per step through the same fused kernel, no halo exchange "
+                         "(replicas; the pool is far larger than the 256-MiB Infinity Cache, so every input comes from HBM)")
+    ap.add_argument("--frames", type=int, default=8, help="--workload batch: frames in each GPU's pool (8 x 8 GPUs = 64)")
     ap.add_argument("--params", default="D", choices=["D", "S", "G", "V", "T"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
@@ -78,8 +83,9 @@ def main():
 
     gpu = R.GpuProcessor(local)
     gpu.set_kernel_variant(args.variant)
-    frame_h = H * world
-    y0, rows = rank * H, H
+    batch = args.workload == "batch"
+    frame_h = H if batch else H * world      # batch: every rank develops whole 6000x4000 frames of its own
+    y0, rows = (0, H) if batch else (rank * H, H)
     praw = R.RawParams(**syn.RAW)
     praw_c = praw.to_c()
     spec = syn.PARAM_SETS[args.params]
@@ -96,7 +102,15 @@ def main():
 
     ed = R.PhotoEditor.for_tile(gpu, W, frame_h, y0, rows)
     configure(ed)
-    dev = tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, configure, rank, world, overlap=not args.no_overlap)
+    dev = tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, configure, rank, 1 if batch else world,
+                              overlap=not args.no_overlap)
+    pool = None
+    if batch:   # rank r holds frames r * frames .. (r + 1) * frames - 1 of the set (seeds 20260630 + i)
+        nframes = max(1, args.frames)
+        cfa = gen(rows, W, seed=20260630 + rank * nframes)          # frame 0 of this rank (the CPU baseline's frame)
+        pool = [tiles.make_band_buffer(cfa, device="cuda")]
+        pool += [tiles.make_band_buffer(gen(rows, W, seed=20260630 + rank * nframes + i), device="cuda")
+                 for i in range(1, nframes)]
     out_fmt, out_bpp = {"rgba": (R.OUT_RGBA_F32, 16), "rgb": (R.OUT_RGB_F32, 12), "u8": (R.OUT_RGB_U8, 3)}[args.out]
     if args.workload != "develop" and args.out != "rgba":
         raise SystemExit("--out applies to the fused develop workload")
@@ -120,7 +134,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    nstep = [0]
+
     def step(i=None):
+        if batch:   # one whole frame of the pool per step: no neighbours, nothing to exchange
+            dev.step(pool[nstep[0] % len(pool)], out, out_fmt, out_bpp, False, ev[i] if i is not None else None)
+            nstep[0] += 1
+            return
         if args.workload == "develop":   # halo exchange (N > 1) hidden behind the interior rows
             dev.step(band, out, out_fmt, out_bpp, True, ev[i] if i is not None else None)
             return
@@ -167,7 +187,7 @@ def main():
     mp_per_step = world * rows * W / 1e6
     value = mp_per_step * args.steps / dt
     bpp = BYTES_PER_PX[args.workload] if args.out == "rgba" else 2 + out_bpp
-    timed_rows = (dev.parts[0][1] if args.workload == "develop" else
+    timed_rows = (dev.parts[0][1] if args.workload in ("develop", "batch") else
                   dev_packed.parts[0][1] if args.workload == "develop_packed" else rows)   # the launch the events bracket
     achieved = bpp * timed_rows * W / (kern_avg_ms * 1e-3) / 1e9   # GB/s, algorithmic bytes of ONE launch
 
@@ -177,14 +197,16 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": (f"{W}x{H} RGGB u16 -> RGBA32F per GPU, fused {args.workload} "
+            "workload": (f"{W}x{H} RGGB u16 -> RGBA32F per GPU, fused {'develop' if batch else args.workload} "
                          f"(demosaic+WB+camera matrix+tone+curves+OKLCH+gamma), edit set {args.params}, "
-                         f"data ({args.data}), frame {W}x{frame_h} in {world} row band(s)"
+                         f"data ({args.data}), "
+                         + (f"batch of {world * len(pool)} different frames, {len(pool)} per GPU, one frame per GPU per step "
+                            f"(replicas, no exchange)" if batch else f"frame {W}x{frame_h} in {world} row band(s)")
                          + (f", {args.masks} masks" if args.masks > 1 else "")
                          + (", REHEARSAL over gloo: ranks may share a GPU, timings are not a measurement"
                             if world > 1 and args.backend != "nccl" else "")
                          + (", 2-row halo exchange per step" + ("" if args.no_overlap else
-                            " hidden behind the interior rows (edge rows launched after it)") if world > 1 else "")),
+                            " hidden behind the interior rows (edge rows launched after it)") if world > 1 and not batch else "")),
             "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps, "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4),
             "kernel_ms_min": round(kern_ms[0], 4),
         },

@@ -299,7 +299,7 @@ typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // one global_load_
 
 // 256-thread builds are launched five workgroups per CU: tell the register allocator (<= 96 VGPRs)
 template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool PACKED = false, bool VIGN = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 5 : (NT == 512 ? 6 : 1))))
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 5 : 1)))
 void k_stream(const StreamArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -838,7 +838,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     // persistent workgroups for the fused kernel (LDS tables staged once per workgroup), as many as are resident: it
     // needs < 96 VGPRs, i.e. 5 waves per SIMD (variant 6: 4, for A/B); the 128-KiB curve in LDS limits that variant
     // to one 1024-thread workgroup per CU
-    uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : (NT == 512 ? 1536 : 1280)) / NT);
+    uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)((cfg.variant == 6 ? 1024 : 1280) / NT);
     if (MODE != MODE_DEMOSAIC) {  // never more than are resident (a register count over 96 would halve the last round)
         // per build (without / with the vignette stage); atomic: two host threads may launch for the first time
         // together (both then store the same value)
@@ -928,8 +928,6 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     if (OUTFMT == OUT_RGBA_F32 && !lut && cfg.variant == 3)  // A/B: the pixel pair one after the other
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
     if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
-        if (ed.mp[0].flags == MF_PRISTINE && cfg.variant == 13)  // A/B: three 512-thread workgroups per CU (6 waves per SIMD)
-            return run_stream<512, MODE_DEVELOP_1P, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
         if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // variant 12 (A/B): run-time flags also for a pristine "main"
             return run_stream<256, MODE_DEVELOP_1P, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
         if ((ed.mp[0].flags & MF_HUE_IDENTITY) && cfg.variant != 11)  // variant 11 (A/B): sincos_hue also for an identity hue curve

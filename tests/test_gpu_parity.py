@@ -548,12 +548,14 @@ def test_incremental_setter_traffic(gpu):
     check()
 
 
-def test_bench_prints_one_contract_line(gpu, capsys, monkeypatch):
-    """bench.py's output contract: ONE JSON line with the fields the driver and the judge read."""
+@pytest.mark.parametrize("extra", [[], ["--workload", "batch", "--frames", "3"]])
+def test_bench_prints_one_contract_line(gpu, capsys, monkeypatch, extra):
+    """bench.py's output contract: ONE JSON line with the fields the driver and the judge read (the headline workload,
+    and BASELINE configs[4]'s batch of different frames)."""
     import importlib
     import json
     import sys
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "6", "--warmup", "2", "--preheat", "4", "--cpu-seconds", "0.5"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "6", "--warmup", "2", "--preheat", "4", "--cpu-seconds", "0.5"] + extra)
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     bench = importlib.import_module("bench")
