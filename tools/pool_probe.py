@@ -1,0 +1,40 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rawphotoforge_amd as R
+from rawphotoforge_amd import synthetic as syn, tiles
+W, H = 6000, 4000
+gpu = R.GpuProcessor(0)
+praw = R.RawParams(**syn.RAW)
+stream = torch.cuda.current_stream().cuda_stream
+ed = R.PhotoEditor.for_tile(gpu, W, H, 0, H)
+syn.configure(ed, syn.PARAM_SETS["D"])
+out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+cfa = syn.bayer_uniform(H, W)
+one = tiles.make_band_buffer(cfa, device="cuda")
+def run(label, bufs, between=None, n=200):
+    for i in range(50):
+        ed.dev_develop(bufs[i % len(bufs)].data_ptr(), praw, out.data_ptr(), R.OUT_RGBA_F32, stream)
+        if between: between()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i in range(n):
+        evs[i][0].record()
+        ed.dev_develop(bufs[i % len(bufs)].data_ptr(), praw, out.data_ptr(), R.OUT_RGBA_F32, stream)
+        evs[i][1].record()
+        if between: between()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in evs)
+    print(f"{label:60s} avg {sum(t)/len(t):.4f} ms  min {t[0]:.4f}", flush=True)
+run("one frame", [one])
+# 16 frames in ONE contiguous allocation (same data in each: what matters is the address range)
+big = torch.empty((16, H + 4, W), dtype=torch.int16, device="cuda")
+for i in range(16): big[i].copy_(one)
+run("16 copies of the frame, one contiguous 768-MB tensor", [big[i] for i in range(16)])
+run("4 copies, contiguous", [big[i] for i in range(4)])
+run("6 copies, contiguous", [big[i] for i in range(6)])
+# one frame, but a 512-MB read-only sweep between launches (evicts the Infinity Cache)
+junk = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+sink = torch.zeros(1, dtype=torch.int64, device="cuda")
+run("one frame, 512-MB sum between launches", [one], between=lambda: sink.add_(junk.view(torch.int64)[::8].sum()), n=60)
+run("one frame again", [one])
