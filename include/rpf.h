@@ -215,6 +215,12 @@ typedef struct rpf_tile {
     uint32_t y0, rows;
 } rpf_tile;
 
+/* Streaming read of a device buffer that was just written by someone else (an upload, a decoder, a halo exchange):
+ * lands it in the GPU's 256-MiB Infinity Cache.  Optional and value-neutral — results never depend on it; a frame that
+ * comes from HBM costs the fused kernel more than this pass does.  No reference counterpart (wgpu leaves
+ * residency to the driver). */
+int rpf_dev_prefetch(rpf_processor* p, const void* d_buf, size_t bytes, void* stream);
+
 /* Packed RAW -> u16 CFA plane (integer, bit-exact).  order RPF_PACK_MSB_FIRST: sample i of a row occupies bits
  * [i*bits, (i+1)*bits) counted from the most significant bit of byte 0 (a big-endian bit stream);
  * RPF_PACK_LSB_FIRST: the same bit positions counted from the least significant bit of byte 0, least significant

@@ -102,6 +102,7 @@ SYMBOLS = {
     "rpf_editor_get_gpu_params": (C.c_int, [_vp, _cs, _P(GpuEditParameters)]),
     "rpf_editor_get_curve": (C.c_int, [_vp, C.c_int, _cs, _i32p]),
     "rpf_pchip_interpolate_i32": (C.c_int, [_i32p, _sz, _i32p, _sz, _i32p, _sz, _i32p, _i32p]),
+    "rpf_dev_prefetch": (C.c_int, [_vp, _vp, _sz, _vp]),
     "rpf_dev_unpack_bayer": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "rpf_dev_rgb16be_to_rgba_f32": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "rpf_dev_demosaic": (C.c_int, [_vp, _vp, _P(RawParams), _P(Tile), _vp, _vp]),

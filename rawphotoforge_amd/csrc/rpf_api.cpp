@@ -768,6 +768,14 @@ int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_s
     return ok();
 }
 
+int rpf_dev_prefetch(rpf_processor* p, const void* d_buf, size_t bytes, void* stream)
+{
+    if (!p || (!d_buf && bytes)) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(launch_touch(d_buf, bytes, p->num_cus, (hipStream_t)stream));
+    return ok();
+}
+
 int rpf_dev_rgb16be_to_rgba_f32(rpf_processor* p, const uint8_t* d_rgb16be, size_t npix, float* d_rgba_out, void* stream)
 {
     if (!p || !d_rgb16be || !d_rgba_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");

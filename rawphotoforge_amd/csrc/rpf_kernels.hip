@@ -714,6 +714,23 @@ __global__ __launch_bounds__(256) void k_resize(const float4* src, uint32_t sw, 
 }
 
 // ---------------------------------------------------------------------------
+// k_touch — a streaming read of a buffer that was just written by somebody else (an upload, a decoder, the halo
+// exchange): it lands the buffer in the 256-MiB Infinity Cache, from where the fused kernel's narrow row loads (128 B
+// per wave-instruction, spread over its whole run time and interleaved with 2 TB/s of stores) come back much faster than
+// from HBM: measured, a 6000x4000 frame fresh from HBM costs the fused kernel +37 us, this pass ~11 us
+// (profiles/r02_experiments.md).  16 B per lane, grid-stride; the values only have to be consumed.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_touch(const uint4* p, size_t n16)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    asm volatile("" ::"v"(acc));  // consumed: the loads cannot be dropped
+}
+
+// ---------------------------------------------------------------------------
 // k_unpack — packed RAW (10/12/14/16-bit; MSB-first bit stream, or LSB-first = little-endian) -> u16 CFA plane.
 // Integer, bit-exact.
 // One thread = 16 samples = 2*BITS bytes read as BITS/2 dwords and two 16-B stores; a group that is
@@ -1090,6 +1107,20 @@ hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t wi
         break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_touch(const void* d_buf, size_t bytes, int num_cus, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    if (!d_buf) return hipErrorInvalidValue;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_buf);
+    const uintptr_t lo = (a + 15) & ~(uintptr_t)15, hi = (a + bytes) & ~(uintptr_t)15;  // whole 16-byte words inside
+    if (hi <= lo) return hipSuccess;
+    const size_t n16 = (hi - lo) / 16;
+    const size_t want = (n16 + 255) / 256;
+    const uint32_t grid = (uint32_t)(want < (size_t)num_cus * 8 ? want : (size_t)num_cus * 8);
+    hipLaunchKernelGGL(k_touch, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(lo), n16);
     return hipGetLastError();
 }
 

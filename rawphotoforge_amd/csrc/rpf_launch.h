@@ -52,6 +52,8 @@ hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom&
 // packed RAW (10/12/14/16 bits, MSB-first or LSB-first bit stream per `order`) -> u16 plane of pitch `width`
 hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows, uint32_t bits,
                          uint32_t order, uint16_t* d_out, hipStream_t s);
+// streaming read of a freshly written buffer (lands it in the Infinity Cache ahead of the fused kernel)
+hipError_t launch_touch(const void* d_buf, size_t bytes, int num_cus, hipStream_t s);
 // bilinear resize of the preview pyramid (web/main.ts:958-1026), RGBA32F -> RGBA32F
 hipError_t launch_resize(const float* d_src, uint32_t sw, uint32_t sh, float* d_dst, uint32_t dw, uint32_t dh, hipStream_t s);
 // RGBA32F -> RGB f32 / RGB u8 repack (image.rs:202-277, 375-383)

@@ -402,6 +402,11 @@ def dev_demosaic(processor: GpuProcessor, d_cfa_ptr: int, raw: RawParams, frame_
                                     C.c_void_p(d_rgba_ptr), C.c_void_p(stream)))
 
 
+def dev_prefetch(processor: GpuProcessor, d_ptr: int, nbytes: int, stream: int = 0) -> None:
+    """Streaming read of a freshly written device buffer: lands it in the Infinity Cache (rpf_dev_prefetch)."""
+    _check(N.lib().rpf_dev_prefetch(processor._h, C.c_void_p(d_ptr), nbytes, C.c_void_p(stream)))
+
+
 def ppm16_parse_header(file_bytes):
     """(width, height, data_offset) of a 16-bit P6 PPM, with loadPpm's header grammar (image.ts:146-170)."""
     a = np.frombuffer(bytes(file_bytes), dtype=np.uint8)

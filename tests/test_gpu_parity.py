@@ -370,6 +370,20 @@ def test_processor_outlives_its_handle_while_editors_exist():
     lib.rpf_editor_destroy(ed)                 # last reference: frees the processor
 
 
+def test_dev_prefetch_is_value_neutral(gpu):
+    """rpf_dev_prefetch only reads: any size / alignment (whole 16-byte words inside the range), nothing changes."""
+    torch = pytest.importorskip("torch")
+    buf = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
+    before = buf.clone()
+    s = torch.cuda.current_stream().cuda_stream
+    for off, nbytes in ((0, buf.numel() * 4), (0, 0), (4, 1000), (12, 15), (1, 17), (3, (1 << 22) - 7)):
+        R.dev_prefetch(gpu, buf.data_ptr() + off, nbytes, s)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, before)
+    with pytest.raises(R.InvalidArgument):
+        R.dev_prefetch(gpu, 0, 64, s)
+
+
 def test_empty_and_invalid_inputs(gpu):
     with pytest.raises(R.FailedToReadImage):
         R.PhotoEditor.new_from_rgb_f32(gpu, np.zeros(0, np.float32), 0, 0)

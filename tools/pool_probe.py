@@ -38,3 +38,51 @@ junk = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 sink = torch.zeros(1, dtype=torch.int64, device="cuda")
 run("one frame, 512-MB sum between launches", [one], between=lambda: sink.add_(junk.view(torch.int64)[::8].sum()), n=60)
 run("one frame again", [one])
+# the demosaic-only kernel (store-bound, 6.2 TB/s with a cached input) on the same pools
+def run_dem(label, bufs, n=200):
+    for i in range(50):
+        R.dev_demosaic(gpu, bufs[i % len(bufs)].data_ptr(), praw, W, H, 0, H, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i in range(n):
+        evs[i][0].record()
+        R.dev_demosaic(gpu, bufs[i % len(bufs)].data_ptr(), praw, W, H, 0, H, out.data_ptr(), stream)
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in evs)
+    print(f"demosaic: {label:50s} avg {sum(t)/len(t):.4f} ms  min {t[0]:.4f}", flush=True)
+run_dem("one frame", [one])
+run_dem("16 copies, contiguous", [big[i] for i in range(16)])
+run_dem("4 copies", [big[i] for i in range(4)])
+# a wide read of the NEXT frame (a torch reduction: 16 B per lane) before it is developed: does that bring the frame into
+# the Infinity Cache, and does the fused kernel then run at its cached-input speed?
+side = torch.cuda.Stream()
+acc = torch.zeros(1, dtype=torch.int64, device="cuda")
+def touch(buf):
+    acc.add_(buf.view(torch.int64).sum())
+def run_touch(label, bufs, overlap, n=200):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    cur = torch.cuda.current_stream()
+    t_all0, t_all1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    touch(bufs[0]); torch.cuda.synchronize()
+    t_all0.record()
+    for i in range(n):
+        nxt = bufs[(i + 1) % len(bufs)]
+        if overlap:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                touch(nxt)
+        evs[i][0].record()
+        ed.dev_develop(bufs[i % len(bufs)].data_ptr(), praw, out.data_ptr(), R.OUT_RGBA_F32, stream)
+        evs[i][1].record()
+        if overlap:
+            cur.wait_stream(side)
+        else:
+            touch(nxt)
+    t_all1.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in evs)
+    print(f"touch-next ({'side stream' if overlap else 'same stream'}): {label:30s} kernel avg {sum(t)/len(t):.4f} ms  min {t[0]:.4f}; "
+          f"whole step {t_all0.elapsed_time(t_all1)/n:.4f} ms", flush=True)
+run_touch("16 copies", [big[i] for i in range(16)], False)
+run_touch("16 copies", [big[i] for i in range(16)], True)
