@@ -592,7 +592,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float4*>(a.in) + base, 0, (int)(span(base) * 16u), RPF_BUFFER_RSRC_FLAGS);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) nxt[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, ((uint32_t)k * NT + tid) * 16u, 0, 0);
+        for (int k = 0; k < 2; ++k) nxt[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, ((uint32_t)k * NT + tid) * 16u, 0, 2);
     };
     uint32_t base = blockIdx.x * NT * 2;
     if (!LENS && base < npix) fetch(base);
