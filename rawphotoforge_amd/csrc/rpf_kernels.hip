@@ -146,7 +146,7 @@ __device__ __forceinline__ void store_px_buf(__amdgpu_buffer_rsrc_t rs, uint32_t
     } else if (OUTFMT == OUT_RGBA_F32_PLAIN) {
         __builtin_amdgcn_raw_buffer_store_b128(v4u{f2bits(r), f2bits(g), f2bits(b), 0x3f800000u}, rs, off, 0, 0);
     } else if (OUTFMT == OUT_RGB_F32) {  // image.rs:202-277
-        __builtin_amdgcn_raw_buffer_store_b96(v3u{f2bits(r), f2bits(g), f2bits(b)}, rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(v3u{f2bits(r), f2bits(g), f2bits(b)}, rs, off, 0, 2);  // nontemporal, like RGBA
     } else {  // image.rs:375-383: (v.clamp(0,1) * 255.0) as u8
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(clamp01(r) * 255.0f), rs, off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(clamp01(g) * 255.0f), rs, off + 1u, 0, 0);
