@@ -14,12 +14,17 @@ LIB = os.path.join(HERE, "gpu_math", "librpf_gpu_math_check.so")
 HDR = os.path.join(HERE, "..", "rawphotoforge_amd", "csrc", "rpf_math.h")
 
 
-@pytest.fixture(scope="module")
-def checker():
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+def build_checker(force=False) -> str:
+    """hipcc cross-compiles the checker without a GPU (also called by __graft_entry__.build)."""
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
         subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--offload-arch=gfx950", "-O3",
                         "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", SRC, "-o", LIB], check=True)
-    lib = C.CDLL(LIB)
+    return LIB
+
+
+@pytest.fixture(scope="module")
+def checker():
+    lib = C.CDLL(build_checker())
     lib.gpu_check_sqrt.restype = C.c_int
     lib.gpu_check_sqrt.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     return lib
