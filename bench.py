@@ -44,6 +44,9 @@ def main():
                     help="develop = BASELINE configs[2] (the headline); batch = configs[4]: a pool of --frames different "
                          "6000x4000 frames per GPU, one whole frame per step through the same fused kernel, no halo exchange "
                          "(replicas; the pool is far larger than the 256-MiB Infinity Cache, so every input comes from HBM)")
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE configs[3]: ONE 12000x8000 frame row-tiled over the N ranks (strong scaling; bands of "
+                         "8000/N rows on even boundaries) instead of the default weak scaling (a 6000x4000 band per rank)")
     ap.add_argument("--frames", type=int, default=8, help="--workload batch: frames in each GPU's pool (8 x 8 GPUs = 64)")
     ap.add_argument("--params", default="D", choices=["D", "S", "G", "V", "T"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
@@ -89,8 +92,16 @@ def main():
     gpu = R.GpuProcessor(local)
     gpu.set_kernel_variant(args.variant)
     batch = args.workload == "batch"
-    frame_h = H if batch else H * world      # batch: every rank develops whole 6000x4000 frames of its own
-    y0, rows = (0, H) if batch else (rank * H, H)
+    global W, H
+    if args.strong:
+        if args.workload not in ("develop", "develop_packed", "demosaic"):
+            raise SystemExit("--strong applies to the row-tiled workloads")
+        W, H = 12000, 8000
+        frame_h = H
+        y0, rows = tiles.split_rows(H, world)[rank]
+    else:
+        frame_h = H if batch else H * world      # batch: every rank develops whole 6000x4000 frames of its own
+        y0, rows = (0, H) if batch else (rank * H, H)
     praw = R.RawParams(**syn.RAW)
     praw_c = praw.to_c()
     spec = syn.PARAM_SETS[args.params]
@@ -194,7 +205,7 @@ def main():
 
     kern_ms = sorted(e[0].elapsed_time(e[1]) for e in ev if e is not None)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    mp_per_step = world * rows * W / 1e6
+    mp_per_step = (frame_h if args.strong else world * rows) * W / 1e6   # the whole job: all ranks' pixels per step
     value = mp_per_step * args.steps / dt
     bpp = BYTES_PER_PX[args.workload] if args.out == "rgba" else 2 + out_bpp
     timed_rows = (dev.parts[0][1] if args.workload in ("develop", "batch") else
@@ -204,10 +215,12 @@ def main():
     result = {
         "metric": "megapixels/sec full RAW\u2192sRGB chain, 6000\u00d74000 Bayer; % HBM roofline",   # BASELINE.json, verbatim
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": (f"{W}x{H} RGGB u16 -> RGBA32F per GPU, fused {'develop' if batch else args.workload} "
+            "workload": ((f"ONE {W}x{H} frame in {world} row band(s) of ~{H // world} rows, " if args.strong else "")
+                         + f"{W}x{rows} RGGB u16 -> RGBA32F per GPU, fused {'develop' if batch else args.workload} "
                          f"(demosaic+WB+camera matrix+tone+curves+OKLCH+gamma), edit set {args.params}, "
                          f"data ({args.data}), "
                          + (f"batch of {world * len(pool)} different frames, {len(pool)} per GPU, one frame per GPU per step "
@@ -232,7 +245,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             tr = json.load(f).get(args.workload)
-        if tr and world == 1 and args.params == "D" and args.data == "U":
+        if tr and world == 1 and args.params == "D" and args.data == "U" and not args.strong:
             result["roofline"]["traffic"] = tr["traffic_bytes"]
             result["roofline"]["traffic_unit"] = "HBM bytes per launch (algorithmic: %d)" % (bpp * rows * W)
             result["roofline"]["traffic_source"] = tr["source"]
@@ -256,7 +269,7 @@ def main():
             pass
         O.set_threads(cores)
         O.develop(cfa, raw, [p], y0=0, rows=64)            # warm the library / thread pool
-        host_out = np.zeros((H, W, 4), np.float32)          # allocated and touched once, like the GPU's output
+        host_out = np.zeros((rows, W, 4), np.float32)       # allocated and touched once, like the GPU's output
         times = []
         t_end = time.perf_counter() + args.cpu_seconds
         while not times or (time.perf_counter() < t_end and len(times) < 20):
@@ -267,7 +280,7 @@ def main():
         # the same frame on ONE thread, on a bounded band, for the per-core figure
         O.set_threads(1)
         t1 = time.perf_counter()
-        O.develop(cfa, raw, [p], y0=(H - args.cpu_rows) // 2 & ~1, rows=args.cpu_rows)
+        O.develop(cfa, raw, [p], y0=(rows - args.cpu_rows) // 2 & ~1, rows=args.cpu_rows)
         c1 = time.perf_counter() - t1
         # BASELINE configs[0]: python-legacy's CPU path (demosaic + WB + apply_gamma((2.222, 4.5)), editor.py:47-76) on a
         # 512x512 frame, as restated in the oracle (pinned by tests/golden/legacy_helpers.npz), 1 thread / all cores
@@ -284,9 +297,9 @@ def main():
             legacy[nthreads] = 512 * 512 / 1e6 / sorted(ts)[len(ts) // 2]
         O.set_threads(cores)
         result["cpu_baseline"] = {
-            "value": round(W * H / 1e6 / ct, 3), "unit": "MP/s", "cores": cores, "kind": "port",
+            "value": round(W * rows / 1e6 / ct, 3), "unit": "MP/s", "cores": cores, "kind": "port",
             "sample": (f"oracle/rpf_oracle.c (C restatement of the same chain, OpenMP, {cores} threads) on the whole "
-                       f"{W}x{H} frame, median of {len(times)} passes ({sum(times):.1f} s wall, "
+                       f"{W}x{rows} frame, median of {len(times)} passes ({sum(times):.1f} s wall, "
                        f"{sum(times) * cores:.0f} core-s); single thread on {args.cpu_rows} rows: "
                        f"{args.cpu_rows * W / 1e6 / c1:.3f} MP/s; python-legacy flavour (demosaic + WB + apply_gamma) "
                        f"on 512x512: {legacy[1]:.1f} MP/s on 1 thread, {legacy[cores]:.1f} MP/s on {cores}"),
