@@ -115,7 +115,8 @@ struct rpf_editor {
     // device copy of the edit state
     uint16_t* d_bright = nullptr;
     ushort4* d_hsl = nullptr;
-    uint8_t* d_masks = nullptr;
+    uint8_t* d_masks = nullptr;       // user-mask planes as uploaded (u8, binarised)
+    uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
     uint32_t lut_capacity = 0;    // masks worth of LUT storage
     uint32_t mask_capacity = 0;   // user-mask planes allocated
     uint64_t uploaded_params = 0, uploaded_masks = 0;
@@ -219,11 +220,16 @@ static int sync_edit_state_impl(rpf_editor* e)
             HIP_TRY(hipMalloc((void**)&e->d_masks, plane * planes));
             e->mask_capacity = planes;
         }
+        if (planes && !e->d_mask_bits) HIP_TRY(hipMalloc((void**)&e->d_mask_bits, plane * sizeof(uint16_t)));
         if (planes && (rc = quiesce())) return rc;
         for (uint32_t m = 1; m < n; ++m)
             HIP_TRY(hipMemcpy(e->d_masks + (size_t)(m - 1) * plane, e->state.masks[m].binary.data(), plane,
                               hipMemcpyHostToDevice));
-        e->dev.mask_planes = planes ? e->d_masks : nullptr;
+        if (planes) {  // (after quiesce(): nothing is in flight; the editor's stream orders it before the next apply)
+            HIP_TRY(launch_combine_masks(e->d_masks, planes, plane, e->d_mask_bits, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));  // rpf_dev_* callers launch on their own streams
+        }
+        e->dev.mask_bits = planes ? e->d_mask_bits : nullptr;
         e->uploaded_masks = e->state.masks_version;
     }
     return ok();
@@ -380,7 +386,7 @@ void rpf_editor_destroy(rpf_editor* e)
     if (!e) return;
     if (e->proc && hipSetDevice(e->proc->device) == hipSuccess) {
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks};
+        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         if (e->stream) (void)hipStreamDestroy(e->stream);

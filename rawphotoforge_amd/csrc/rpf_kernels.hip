@@ -165,10 +165,9 @@ __device__ __forceinline__ void store_px_row(void* out, size_t row_pix, uint32_t
 
 __device__ __forceinline__ uint32_t active_masks(const DeviceEdit& ed, size_t pix, size_t plane)
 {
-    uint32_t active = 1u;  // "main" is all ones by construction (lib.rs:193-196)
-    for (uint32_t m = 1; m < ed.num_masks; ++m)
-        active |= (uint32_t)(ed.mask_planes[(size_t)(m - 1) * plane + pix] == 1) << m;
-    return active;
+    (void)plane;
+    // bit 0: "main" is all ones by construction (lib.rs:193-196); bits 1..: the user masks' combined bit plane
+    return 1u | ((uint32_t)ed.mask_bits[pix] << 1);
 }
 
 __device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T, uint16_t* lut, bool with_lut, int tid,
@@ -660,6 +659,16 @@ __global__ __launch_bounds__(256) void k_repack(const float4* in, size_t npix, v
     }
 }
 
+// user-mask planes (u8, 1 = covered) -> one u16 of mask bits per pixel (DeviceEdit::mask_bits)
+__global__ __launch_bounds__(256) void k_combine_masks(const uint8_t* planes, uint32_t nplanes, size_t npix, uint16_t* bits)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        uint32_t v = 0;
+        for (uint32_t m = 0; m < nplanes; ++m) v |= (uint32_t)(planes[(size_t)m * npix + i] == 1) << m;
+        bits[i] = (uint16_t)v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pad_rgb(const float* in, size_t npix, float4* out)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256)
@@ -822,7 +831,7 @@ static hipError_t check_geom(const TileGeom& g, bool bayer)
 static hipError_t check_edit(const DeviceEdit& ed)
 {
     if (!ed.tabs || !ed.hue_bounds || !ed.hue_cs || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS) return hipErrorInvalidValue;
-    if (ed.num_masks > 1 && !ed.mask_planes) return hipErrorInvalidValue;
+    if (ed.num_masks > 1 && !ed.mask_bits) return hipErrorInvalidValue;
     return hipSuccess;
 }
 
@@ -1162,6 +1171,15 @@ hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_
                            npix, d_out);
     else
         return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_combine_masks(const uint8_t* d_planes, uint32_t planes, size_t npix, uint16_t* d_bits, hipStream_t s)
+{
+    if (npix == 0 || planes == 0) return hipSuccess;
+    if (!d_planes || !d_bits || planes > RPF_MAX_MASKS - 1) return hipErrorInvalidValue;
+    const uint32_t grid = (uint32_t)((npix + 255) / 256 > 8192 ? 8192 : (npix + 255) / 256);
+    hipLaunchKernelGGL(k_combine_masks, dim3(grid), dim3(256), 0, s, d_planes, planes, npix, d_bits);
     return hipGetLastError();
 }
 

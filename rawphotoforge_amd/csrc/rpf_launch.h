@@ -10,7 +10,10 @@ namespace rpf {
 struct DeviceEdit {
     MaskParams mp[RPF_MAX_MASKS];
     uint32_t num_masks;
-    const uint8_t* mask_planes;  // (num_masks - 1) planes of rows*width u8 (user masks), or null
+    // One u16 per pixel of the tile: bit m - 1 set <=> user mask m covers the pixel (its binarised value is 1.0,
+    // lib.rs:483-486); null when there are no user masks.  ONE load per pixel whatever the number of masks — per-mask u8
+    // planes cost the kernel a dependent round trip to memory per mask per step.
+    const uint16_t* mask_bits;
     const uint16_t* bright;      // num_masks x 65536 u16, clamped (wgsl:188)
     const ushort4* hsl;          // num_masks x 65536 {hue, sat, light, 0}
     const MathTables* tabs;
@@ -58,6 +61,8 @@ hipError_t launch_touch(const void* d_buf, size_t bytes, int num_cus, hipStream_
 hipError_t launch_resize(const float* d_src, uint32_t sw, uint32_t sh, float* d_dst, uint32_t dw, uint32_t dh, hipStream_t s);
 // RGBA32F -> RGB f32 / RGB u8 repack (image.rs:202-277, 375-383)
 hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_format, hipStream_t s);
+// (planes) u8 mask planes of npix pixels, value 1 = covered -> the u16 bit plane DeviceEdit::mask_bits points at
+hipError_t launch_combine_masks(const uint8_t* d_planes, uint32_t planes, size_t npix, uint16_t* d_bits, hipStream_t s);
 // interleaved RGB f32 -> RGBA32F, alpha = 1 (image.rs:135-139)
 hipError_t launch_pad_rgb(const float* d_rgb, size_t npix, float* d_rgba, hipStream_t s);
 hipError_t launch_rgb16be(const uint8_t* d_in, size_t npix, float* d_rgba, hipStream_t s);
