@@ -215,6 +215,10 @@ RPF_HD void mask_rgb_stage(const MaskParams& PP, uint32_t m, const Luts& luts, f
     struct Flags { uint32_t flags; };
     const Flags P{STATIC_FLAGS >= 0 ? (uint32_t)STATIC_FLAGS : PP.flags};
     const float inv65535 = (float)(1.0 / 65535.0);
+    // Three phases over all N pixels — tone, curve fetch, result — rather than pixel after pixel: the flag tests are
+    // wave-uniform branches, and with the pixels' curve gathers in ONE branch they are issued back to back and waited
+    // for once (pixel by pixel, every user mask cost two dependent round trips to the curve table per step).
+    float xk[N], yk[N], zk[N];
     for (int n = 0; n < N; ++n) {
         float x = r[n], y = g[n], z = b[n];
         // White balance (wgsl:285-288) and exposure (wgsl:214-215).  x * 1.0f == x exactly, so the unity flags only
@@ -250,19 +254,27 @@ RPF_HD void mask_rgb_stage(const MaskParams& PP, uint32_t m, const Luts& luts, f
             z = (z - 0.5f) * PP.contrast_c + 0.5f;
         }
         x = clamp01(x); y = clamp01(y); z = clamp01(z);
-        // brightness curve, wgsl:293-305
-        // f32(u32(v)) for v in [0, 65535] is trunc(v): with the identity curve no integer is needed at all
-        float xk = x * 65535.0f, yk = y * 65535.0f, zk = z * 65535.0f;
-        if (!(P.flags & MF_BRIGHT_IDENTITY)) {
-            xk = (float)luts.brightness(m, (uint32_t)xk);
-            yk = (float)luts.brightness(m, (uint32_t)yk);
-            zk = (float)luts.brightness(m, (uint32_t)zk);
-        } else {
-            xk = __builtin_truncf(xk); yk = __builtin_truncf(yk); zk = __builtin_truncf(zk);
+        xk[n] = x * 65535.0f; yk[n] = y * 65535.0f; zk[n] = z * 65535.0f;
+    }
+    // brightness curve, wgsl:293-305
+    // f32(u32(v)) for v in [0, 65535] is trunc(v): with the identity curve no integer is needed at all
+    if (!(P.flags & MF_BRIGHT_IDENTITY)) {
+        uint32_t xi[N], yi[N], zi[N];
+        for (int n = 0; n < N; ++n) {
+            xi[n] = luts.brightness(m, (uint32_t)xk[n]);
+            yi[n] = luts.brightness(m, (uint32_t)yk[n]);
+            zi[n] = luts.brightness(m, (uint32_t)zk[n]);
         }
-        x = div_u16f_by(xk, 65535.0f, inv65535);
-        y = div_u16f_by(yk, 65535.0f, inv65535);
-        z = div_u16f_by(zk, 65535.0f, inv65535);
+        for (int n = 0; n < N; ++n) { xk[n] = (float)xi[n]; yk[n] = (float)yi[n]; zk[n] = (float)zi[n]; }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            xk[n] = __builtin_truncf(xk[n]); yk[n] = __builtin_truncf(yk[n]); zk[n] = __builtin_truncf(zk[n]);
+        }
+    }
+    for (int n = 0; n < N; ++n) {
+        const float x = div_u16f_by(xk[n], 65535.0f, inv65535);
+        const float y = div_u16f_by(yk[n], 65535.0f, inv65535);
+        const float z = div_u16f_by(zk[n], 65535.0f, inv65535);
         const bool on = act ? act[n] : true;
         r[n] = on ? x : r[n]; g[n] = on ? y : g[n]; b[n] = on ? z : b[n];
     }
@@ -274,13 +286,20 @@ RPF_HD void mask_rgb_stage(const MaskParams& PP, uint32_t m, const Luts& luts, f
 // HUE_DIRECT (the caller's promise: num_masks == 1 and "main"'s hue curve is the identity): the index the hue
 // becomes IS the new hue, and cos / sin of its angle come with the boundary-table entry (hue_index_cs) instead of
 // being evaluated by sincos_hue.  A compile-time choice: as a run-time branch it splits the pair's gathers again.
+// Where a mask's uniform parameters come from.  A plain array (the host twin, single-mask kernels) ...
+RPF_HD const MaskParams& mask_params_main(const MaskParams* mp) { return mp[0]; }
+RPF_HD const MaskParams& mask_params_user(const MaskParams* mp, uint32_t m) { return mp[m]; }
+// ... or, in the multi-mask kernels, a source that serves the user masks' parameters from LDS (rpf_kernels.hip
+// LdsMaskParams): read through the kernel-argument pointer inside the per-mask loop, every field is a scalar load of
+// its own with its own wait, per mask per pixel.
+
 // STATIC_FLAGS (>= 0): "main"'s flag word, known at compile time (the caller's promise that mp[0].flags equals it).
-template <int N, bool HUE_DIRECT = false, int STATIC_FLAGS = -1, class Luts, class Tabs>
+template <int N, bool HUE_DIRECT = false, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
 RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],
-                       const MaskParams* mp, uint32_t num_masks, const Luts& luts, const Tabs& T)
+                       const Params& mp, uint32_t num_masks, const Luts& luts, const Tabs& T)
 {
     const float inv65535 = (float)(1.0 / 65535.0);
-    mask_rgb_stage<N, STATIC_FLAGS>(mp[0], 0u, luts, r, g, b, nullptr);  // "main" is all ones (lib.rs:193-196)
+    mask_rgb_stage<N, STATIC_FLAGS>(mask_params_main(mp), 0u, luts, r, g, b, nullptr);  // "main" is all ones (lib.rs:193-196)
     // bits of the user masks that cover at least one pixel of this wavefront: a mask that covers none is skipped
     // as a whole (wgsl:281 `continue` for every lane) — masks are regions, most wavefronts lie inside or outside
     uint32_t any_active = 0;
@@ -297,7 +316,7 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         if (!((any_active >> m) & 1u)) continue;
         bool act[N];
         for (int n = 0; n < N; ++n) act[n] = (active[n] >> m) & 1u;
-        mask_rgb_stage<N>(mp[m], m, luts, r, g, b, act);
+        mask_rgb_stage<N>(mask_params_user(mp, m), m, luts, r, g, b, act);
     }
 
     // linear_srgb_to_oklch, wgsl:64-75.  The hue is only ever used as a curve index (hue_index, rpf_math.h).
@@ -330,7 +349,7 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
     // per-mask OKLCH curves, wgsl:312-331
     uint32_t hue_k[N];
     auto oklch_stage = [&](uint32_t m, bool main_mask) {
-        const MaskParams& P = mp[m];
+        const MaskParams P = main_mask ? mask_params_main(mp) : mask_params_user(mp, m);
         const uint32_t pflags = (main_mask && STATIC_FLAGS >= 0) ? (uint32_t)STATIC_FLAGS : P.flags;
         const bool trivial = (pflags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
                              (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);

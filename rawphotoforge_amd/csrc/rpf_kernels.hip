@@ -48,6 +48,36 @@ struct LdsTabs {
     __device__ __forceinline__ LdsTabs(uint32_t base, const MathTables* T)
         : cbrt{base + (uint32_t)offsetof(MathTables, cbrt)}, gamma{base + (uint32_t)offsetof(MathTables, gamma)}, sc(T->sc) {}
 };
+// Mask parameters as the multi-mask kernels read them: "main" through the kernel-argument segment (loaded once, scalar
+// registers), a user mask's 48 bytes from a copy in LDS at byte address `lds_base` with three 16-byte reads per mask per
+// step — wave-uniform values in vector registers, so the tone arithmetic also runs at the full f32 rate (an SGPR operand
+// halves it) — and its flag word made scalar again for the stage's uniform branches.
+struct LdsMaskParams {
+    const MaskParams* karg;
+    uint32_t lds_base;
+};
+__device__ __forceinline__ const MaskParams& mask_params_main(const LdsMaskParams& s) { return s.karg[0]; }
+__device__ __forceinline__ MaskParams mask_params_user(const LdsMaskParams& s, uint32_t m)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) v4u* lds_v4u_ptr;
+    static_assert(sizeof(MaskParams) == 48, "three 16-byte reads");
+    const uint32_t a = s.lds_base + m * 48u;
+    const v4u q0 = *(lds_v4u_ptr)(a), q1 = *(lds_v4u_ptr)(a + 16u), q2 = *(lds_v4u_ptr)(a + 32u);
+    MaskParams P;
+    P.r_gain = bits2f(q0.x); P.g_gain = bits2f(q0.y); P.b_gain = bits2f(q0.z); P.exposure_mul = bits2f(q0.w);
+    P.shadow = bits2f(q1.x); P.highlight = bits2f(q1.y); P.black = bits2f(q1.z); P.white = bits2f(q1.w);
+    P.contrast_c = bits2f(q2.x); P.flags = __builtin_amdgcn_readfirstlane(q2.y);
+    P.sat_gain = bits2f(q2.z); P.light_gain = bits2f(q2.w);
+    return P;
+}
+__device__ __forceinline__ void stage_mask_params(const DeviceEdit& ed, unsigned char* lds, int tid)
+{
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(ed.mp);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+    if (tid < (int)(sizeof(MaskParams) * RPF_MAX_MASKS / 4)) dst[tid] = src[tid];
+}
+
 // The dynamic shared block must start at LDS address 0 for LdsTabs' constant addresses to be right (it does: these
 // kernels declare no static __shared__ variable).  One scalar compare per launch; a mismatch is a build error to be
 // seen, not computed through.
@@ -194,7 +224,8 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
                                             int cy_top, const RawParamsDev& raw, const DeviceEdit& ed,
                                             const DevLuts<LDS_LUT>& luts, const LdsTabs& T, int gx, int ry_top,
                                             const TileGeom& g, bool col_live, void* out, const float* cam,
-                                            float vcx2 = 0.0f, float vcy2_top = 0.0f, float vcy2_bot = 0.0f)
+                                            float vcx2 = 0.0f, float vcy2_top = 0.0f, float vcy2_bot = 0.0f,
+                                            uint32_t lds_mp = 0xffffffffu)  // LDS address of the staged mask parameters
 {
     const bool topA = cx == cy_top;  // top pixel is the R/B site, bottom the G site
     const float cA = topA ? c[0] : c[1], s1A = topA ? s1[0] : s1[1], e1A = topA ? e1[0] : e1[1];
@@ -247,6 +278,8 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
                 edit_chain<1>(r1, g1, b1, a1, ed.mp, ed.num_masks, luts, T);
                 r[k] = r1[0]; gg[k] = g1[0]; b[k] = b1[0];
             }
+        } else if (lds_mp != 0xffffffffu) {
+            edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
         } else {
             edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
         }
@@ -305,9 +338,13 @@ void k_stream(const StreamArgs a)
     MathTables* T = reinterpret_cast<MathTables*>(smem);
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
     const int tid = threadIdx.x;
+    // the multi-mask kernels keep the masks' uniform parameters behind the tables (and the curve)
+    constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
+    constexpr bool MULTI = MODE == MODE_DEVELOP;
     if (MODE != MODE_DEMOSAIC) {
         assert_lds_base(smem);
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+        if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid);
         __syncthreads();  // the only barrier of the kernel
     }
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
@@ -449,7 +486,7 @@ void k_stream(const StreamArgs a)
             }
             finish_pair<MODE, LDS_LUT, OUTFMT, VIGN ? 2 : 0>(c, s1, e1, d, vv, h2, cx, bp, a.raw, a.ed, luts, tabs, xl,
                                                              2 * (pair0 + p), a.g, col_live, a.out, camv, vcx2, vcy2_top,
-                                                             vcy2_bot);
+                                                             vcy2_bot, MULTI ? LDS_MP : 0xffffffffu);
             // slide the window down two rows
             w0 = t2.v; t1 = t3; t2 = t4; t3 = t5;
         }
@@ -567,8 +604,10 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     MathTables* T = reinterpret_cast<MathTables*>(smem);
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
     const int tid = threadIdx.x;
+    constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     assert_lds_base(smem);
     stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+    if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
     const LdsTabs tabs(0u, T);
@@ -638,8 +677,10 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
             edit_chain<2, false, (int)MF_PRISTINE>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else if (SINGLE == 2)
             edit_chain<2, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+        else if (SINGLE == 0)
+            edit_chain<2>(r, g, b, active, LdsMaskParams{a.ed.mp, LDS_MP}, a.ed.num_masks, luts, tabs);
         else
-            edit_chain<2>(r, g, b, active, a.ed.mp, SINGLE ? 1u : a.ed.num_masks, luts, tabs);
+            edit_chain<2>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<unsigned char*>(a.out) + (size_t)base * BPP, 0, (int)(span(base) * BPP), RPF_BUFFER_RSRC_FLAGS);
 #pragma unroll
@@ -853,7 +894,9 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     const uint32_t total_pairs = (g.rows + 1) / 2;
     a.strips = (g.width + STRIP_W - 1) / STRIP_W;
     constexpr uint32_t WPB = NT / 64;
-    const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) : 0;
+    const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
+                                                   (MODE == MODE_DEVELOP ? sizeof(MaskParams) * RPF_MAX_MASKS : 0)
+                                             : 0;
     // two builds of every fused kernel: with the vignette stage (coordinates hoisted per column / per row) and
     // without it (its code and registers compiled out: the plain kernel stays under 96 VGPRs)
     const bool vign = MODE != MODE_DEMOSAIC && ed && ed->vign_strength != 0.0f;
@@ -1045,7 +1088,8 @@ template <bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE>
 static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
 {
     constexpr int NT = LDS_LUT ? 1024 : 256;
-    const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0);
+    const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
+                       (SINGLE == 0 ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
     auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT, SINGLE>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
