@@ -123,6 +123,16 @@ __device__ __forceinline__ float from_left(float v, float edge)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
                                                                  __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
 }
+// the same shifts with zero fill (bound_ctrl): lane 0 / lane 63 receive 0.  No `old` value to preserve, so the
+// compiler does not have to copy one into the destination first.
+__device__ __forceinline__ float from_left0(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_right0(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
 // lane L receives v of lane L+1; lane 63 keeps `edge`
 __device__ __forceinline__ float from_right(float v, float edge)
 {
@@ -316,8 +326,8 @@ struct StreamArgs {
 struct RowTaps { float v, p1, p2; };
 __device__ __forceinline__ RowTaps row_taps(float v, float h, bool need_p2)
 {
-    const float hl1 = from_right(h, h);        // lane 0  <- lane 1's halo  (column x0-1)
-    const float hr1 = from_left(h, h);         // lane 63 <- lane 62's halo (column x0+64)
+    const float hl1 = from_right0(h);          // lane 0  <- lane 1's halo  (column x0-1); the other lanes: unused
+    const float hr1 = from_left0(h);           // lane 63 <- lane 62's halo (column x0+64); the other lanes: unused
     const float l1 = from_left(v, hl1);        // x-1
     const float r1 = from_right(v, hr1);       // x+1
     RowTaps t;
