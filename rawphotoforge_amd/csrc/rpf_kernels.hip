@@ -37,7 +37,9 @@ namespace rpf {
 // (MF_PRISTINE: every slider and curve at the reference default — a photo that was just opened; BASELINE's set D):
 // the flag word is a compile-time constant, so no stage tests, multiplies by or selects on a default.
 enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2, MODE_DEVELOP_1 = 3, MODE_DEVELOP_1H = 4,
-       MODE_DEVELOP_1P = 5 };
+       MODE_DEVELOP_1P = 5,
+       MODE_DEVELOP_MP = 6 };  // _MP: user masks over a pristine "main" (its flag word static, as in _1P)
+constexpr bool mode_multi(int mode) { return mode == MODE_DEVELOP || mode == MODE_DEVELOP_MP; }
 constexpr bool mode_single(int mode) { return mode == MODE_DEVELOP_1 || mode == MODE_DEVELOP_1H || mode == MODE_DEVELOP_1P; }
 
 // The math tables as the kernels address them: by LDS byte address (rpf_math.h LdsPowTable).  `base` = LDS address of
@@ -288,6 +290,8 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
                 edit_chain<1>(r1, g1, b1, a1, ed.mp, ed.num_masks, luts, T);
                 r[k] = r1[0]; gg[k] = g1[0]; b[k] = b1[0];
             }
+        } else if (MODE == MODE_DEVELOP_MP) {
+            edit_chain<2, false, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
         } else if (lds_mp != 0xffffffffu) {
             edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
         } else {
@@ -350,7 +354,7 @@ void k_stream(const StreamArgs a)
     const int tid = threadIdx.x;
     // the multi-mask kernels keep the masks' uniform parameters behind the tables (and the curve)
     constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
-    constexpr bool MULTI = MODE == MODE_DEVELOP;
+    constexpr bool MULTI = mode_multi(MODE);
     if (MODE != MODE_DEMOSAIC) {
         assert_lds_base(smem);
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
@@ -905,7 +909,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     a.strips = (g.width + STRIP_W - 1) / STRIP_W;
     constexpr uint32_t WPB = NT / 64;
     const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
-                                                   (MODE == MODE_DEVELOP ? sizeof(MaskParams) * RPF_MAX_MASKS : 0)
+                                                   (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0)
                                              : 0;
     // two builds of every fused kernel: with the vignette stage (coordinates hoisted per column / per row) and
     // without it (its code and registers compiled out: the plain kernel stays under 96 VGPRs)
@@ -1030,6 +1034,8 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
         return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                    : run_stream<256, MODE_DEVELOP_1, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     }
+    if (!lut && ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // user masks over an untouched "main"
+        return run_stream<256, MODE_DEVELOP_MP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
 }
@@ -1049,6 +1055,8 @@ static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_pack
         return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                    : run_stream<256, MODE_DEVELOP_1, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
     }
+    if (!lut && ed.mp[0].flags == MF_PRISTINE)
+        return run_stream<256, MODE_DEVELOP_MP, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
 }
