@@ -38,8 +38,10 @@ namespace rpf {
 // the flag word is a compile-time constant, so no stage tests, multiplies by or selects on a default.
 enum { MODE_DEMOSAIC = 0, MODE_DEVELOP = 1, MODE_DEVELOP_SEQ = 2, MODE_DEVELOP_1 = 3, MODE_DEVELOP_1H = 4,
        MODE_DEVELOP_1P = 5,
-       MODE_DEVELOP_MP = 6 };  // _MP: user masks over a pristine "main" (its flag word static, as in _1P)
-constexpr bool mode_multi(int mode) { return mode == MODE_DEVELOP || mode == MODE_DEVELOP_MP; }
+       MODE_DEVELOP_MP = 6,    // _MP: user masks over a pristine "main" (its flag word static, as in _1P)
+       MODE_DEVELOP_MPH = 7 }; // _MPH: _MP whose user masks all have identity hue curves as well: HUE_DIRECT (the hue
+                               // index "main" settles survives every mask: u32(f32(k / 65535) * 65535) == k for all k)
+constexpr bool mode_multi(int mode) { return mode == MODE_DEVELOP || mode == MODE_DEVELOP_MP || mode == MODE_DEVELOP_MPH; }
 constexpr bool mode_single(int mode) { return mode == MODE_DEVELOP_1 || mode == MODE_DEVELOP_1H || mode == MODE_DEVELOP_1P; }
 
 // The math tables as the kernels address them: by LDS byte address (rpf_math.h LdsPowTable).  `base` = LDS address of
@@ -290,6 +292,8 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
                 edit_chain<1>(r1, g1, b1, a1, ed.mp, ed.num_masks, luts, T);
                 r[k] = r1[0]; gg[k] = g1[0]; b[k] = b1[0];
             }
+        } else if (MODE == MODE_DEVELOP_MPH) {
+            edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
         } else if (MODE == MODE_DEVELOP_MP) {
             edit_chain<2, false, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
         } else if (lds_mp != 0xffffffffu) {
@@ -867,6 +871,12 @@ static hipError_t set_lds(K kernel, size_t bytes)
                                (int)bytes);
 }
 
+static bool all_hue_identity(const DeviceEdit& ed)
+{
+    for (uint32_t m = 0; m < ed.num_masks; ++m)
+        if (!(ed.mp[m].flags & MF_HUE_IDENTITY)) return false;
+    return true;
+}
 static bool needs_lds_lut(const DeviceEdit& ed) { return !(ed.mp[0].flags & MF_BRIGHT_IDENTITY); }
 
 // Operand checks shared by the launchers: a tile must be non-empty, inside its frame and large
@@ -1034,8 +1044,11 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
         return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                    : run_stream<256, MODE_DEVELOP_1, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     }
-    if (!lut && ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // user masks over an untouched "main"
+    if (!lut && ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12) {  // user masks over an untouched "main"
+        if (all_hue_identity(ed) && cfg.variant != 11)
+            return run_stream<256, MODE_DEVELOP_MPH, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
         return run_stream<256, MODE_DEVELOP_MP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    }
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
 }
@@ -1055,8 +1068,11 @@ static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_pack
         return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                    : run_stream<256, MODE_DEVELOP_1, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
     }
-    if (!lut && ed.mp[0].flags == MF_PRISTINE)
+    if (!lut && ed.mp[0].flags == MF_PRISTINE) {
+        if (all_hue_identity(ed))
+            return run_stream<256, MODE_DEVELOP_MPH, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
         return run_stream<256, MODE_DEVELOP_MP, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+    }
     return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                : run_stream<256, MODE_DEVELOP, false, OUTFMT, true>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
 }

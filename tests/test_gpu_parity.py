@@ -122,6 +122,32 @@ def test_develop_with_user_masks(gpu):
     assert_parity(ed.rgba(), O.develop(cfa, rp, [O.EditParameters()]))
 
 
+def test_user_masks_over_a_pristine_main(gpu):
+    """"main" untouched, only the user masks carry edits: the multi-mask kernels with a compile-time "main"
+    (MODE_DEVELOP_MP; _MPH when every mask's hue curve is the identity, where cos / sin of the hue come with the index
+    "main" settled) against the oracle, overlapping masks included."""
+    h, w = 66, 200
+    cfa = util.bayer_uniform(h, w, seed=31)
+    rp = util.raw_params()
+    rng = np.random.default_rng(9)
+    ma = np.where(rng.random((h, w)) > 0.3, 1.0, -1.0).astype(np.float32)
+    mb = np.full((h, w), -1.0, np.float32)
+    mb[5:60, 40:190] = 1.0
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(ma), O.binarize_mask(mb)])
+    s2 = util.params_S()
+    s2.exposure, s2.contrast = -0.7, 35
+    for pa, pb in ((util.params_S(), s2),                 # identity hue curves everywhere (_MPH)
+                   (util.params_S(), util.params_G())):   # one mask with a hue curve (_MP)
+        ed = bayer_editor(gpu, cfa, rp)
+        ed.add_mask("a", ma)
+        ed.add_mask("b", mb)
+        util.configure_editor(ed, util.params_D())
+        util.configure_editor(ed, pa, "a", main=False)
+        util.configure_editor(ed, pb, "b", main=False)
+        ed.apply_adjustments()
+        assert_parity(ed.rgba(), O.develop(cfa, rp, [util.params_D(), pa, pb], masks=masks))
+
+
 def test_fused_equals_demosaic_then_apply(gpu):
     cfa = util.bayer_natural(96, 200)
     rp = util.raw_params()

@@ -225,3 +225,14 @@ def test_division_by_three_quarters_every_vignette_argument():
             tw.twin_div_const_range(C.c_float(0.75), C.c_uint32(s), C.c_uint32(n), got.ctypes.data_as(C.c_void_p))
             x = np.arange(s, s + n, dtype=np.uint32).view(np.float32)
             assert np.array_equal(got.view(np.uint32), (x / d).view(np.uint32)), hex(s)
+
+
+def test_requantised_hue_index_is_the_identity():
+    """wgsl:320 on a hue that came out of an identity hue curve: u32(f32(k / 65535) * 65535) == k for every k.  This is
+    what lets HUE_DIRECT (cos / sin of the hue read with the index "main" settled) serve launches with user masks whose
+    hue curves are all the identity: the index survives every mask's re-quantisation."""
+    tw = util.twin()
+    k = np.arange(65536, dtype=np.uint32)
+    h = np.array([tw.twin_div_u16(C.c_uint32(int(i)), C.c_float(65535.0)) for i in k], np.float32)
+    assert np.array_equal(h, (k.astype(np.float32) / np.float32(65535.0)).astype(np.float32))
+    assert np.array_equal((h * np.float32(65535.0)).astype(np.float32).astype(np.uint32), k)
