@@ -224,10 +224,13 @@ int rpf_dev_prefetch(rpf_processor* p, const void* d_buf, size_t bytes, void* st
 /* Packed RAW -> u16 CFA plane (integer, bit-exact).  order RPF_PACK_MSB_FIRST: sample i of a row occupies bits
  * [i*bits, (i+1)*bits) counted from the most significant bit of byte 0 (a big-endian bit stream);
  * RPF_PACK_LSB_FIRST: the same bit positions counted from the least significant bit of byte 0, least significant
- * sample bit first (the row read as one little-endian integer).  Rows start every row_stride bytes.
+ * sample bit first (the row read as one little-endian integer);
+ * RPF_PACK_MIPI: MIPI CSI-2 RAW10 / RAW12 / RAW14 — groups of 4 / 2 / 4 pixels in 5 / 3 / 7 bytes, the pixels' high
+ * bytes first, then their bits - 8 low bits LSB-first in pixel order; a row holds whole groups (bits 16 is refused,
+ * and so is this order by rpf_dev_develop_packed: unpack, then rpf_dev_develop).  Rows start every row_stride bytes.
  * bits in {10, 12, 14, 16}.  d_cfa_out has pitch `width` (write it at row 2 of a band buffer).  In the reference
  * this step is inside rawler / LibRaw (rust-godot-legacy/photo-editor/src/image.rs:516-523). */
-enum { RPF_PACK_MSB_FIRST = 0, RPF_PACK_LSB_FIRST = 1 };
+enum { RPF_PACK_MSB_FIRST = 0, RPF_PACK_LSB_FIRST = 1, RPF_PACK_MIPI = 2 };
 int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows,
                          uint32_t bits, uint32_t order, uint16_t* d_cfa_out, void* stream);
 /* npix big-endian 16-bit RGB triplets (2-byte aligned) -> RGBA32F, v / 65535, alpha 1 (image.ts:172-189) */

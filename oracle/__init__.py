@@ -287,21 +287,25 @@ def max_threads() -> int:
     return lib().orc_max_threads()
 
 
-def packed_row_stride(width: int, bits: int, align: int = 4) -> int:
-    n = (width * bits + 7) // 8
+PACK_MSB_FIRST, PACK_LSB_FIRST, PACK_MIPI = 0, 1, 2
+
+
+def packed_row_stride(width: int, bits: int, align: int = 4, order: int = 0) -> int:
+    if order == PACK_MIPI:   # whole groups of 4 (RAW10 / RAW14) or 2 (RAW12) pixels
+        npx = 2 if bits == 12 else 4
+        n = (width + npx - 1) // npx * (npx + npx * (bits - 8) // 8)
+    else:
+        n = (width * bits + 7) // 8
     return (n + align - 1) // align * align
-
-
-PACK_MSB_FIRST, PACK_LSB_FIRST = 0, 1
 
 
 def pack_bayer(cfa, bits: int, row_stride=None, order=PACK_MSB_FIRST) -> np.ndarray:
     """Bit-packing of a (rows, width) u16 plane (test helper; inverse of unpack_bayer)."""
     a = np.ascontiguousarray(cfa, np.uint16)
     rows, w = a.shape
-    stride = row_stride or packed_row_stride(w, bits)
+    stride = row_stride or packed_row_stride(w, bits, order=order)
     out = np.zeros((rows, stride), np.uint8)
-    fn = lib().orc_pack_bayer_lsb if order == PACK_LSB_FIRST else lib().orc_pack_bayer
+    fn = {PACK_LSB_FIRST: lib().orc_pack_bayer_lsb, PACK_MIPI: lib().orc_pack_bayer_mipi}.get(order, lib().orc_pack_bayer)
     fn(_p(a, C.c_uint16), C.c_uint32(w), C.c_uint32(rows), C.c_uint32(bits), C.c_size_t(stride), _p(out, C.c_uint8))
     return out
 
@@ -311,7 +315,7 @@ def unpack_bayer(packed, width: int, bits: int, order=PACK_MSB_FIRST) -> np.ndar
     p = np.ascontiguousarray(packed, np.uint8)
     rows, stride = p.shape
     out = np.empty((rows, width), np.uint16)
-    fn = lib().orc_unpack_bayer_lsb if order == PACK_LSB_FIRST else lib().orc_unpack_bayer
+    fn = {PACK_LSB_FIRST: lib().orc_unpack_bayer_lsb, PACK_MIPI: lib().orc_unpack_bayer_mipi}.get(order, lib().orc_unpack_bayer)
     fn(_p(p, C.c_uint8), C.c_size_t(stride), C.c_uint32(width), C.c_uint32(rows), C.c_uint32(bits), _p(out, C.c_uint16))
     return out
 

@@ -34,7 +34,7 @@ ERR_TOO_MANY_MASKS = 33
 OUT_RGBA_F32, OUT_RGB_F32, OUT_RGB_U8 = 0, 1, 2
 CFA_RGGB, CFA_BGGR, CFA_GRBG, CFA_GBRG = 0, 1, 2, 3
 FLAVOUR_ACTIVE, FLAVOUR_GODOT_LEGACY = 0, 1
-PACK_MSB_FIRST, PACK_LSB_FIRST = 0, 1
+PACK_MSB_FIRST, PACK_LSB_FIRST, PACK_MIPI = 0, 1, 2
 CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
 
 

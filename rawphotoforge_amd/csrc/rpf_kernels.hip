@@ -861,6 +861,62 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, size_t ro
 }
 
 // ---------------------------------------------------------------------------
+// k_unpack_mipi — MIPI CSI-2 RAW10 / RAW12 / RAW14 (RPF_PACK_MIPI) -> u16 CFA plane.  Groups of N = 4 / 2 / 4 pixels in
+// 5 / 3 / 7 bytes: N high bytes, then the pixels' BITS - 8 low bits LSB-first in pixel order.  16 samples are 2*BITS
+// bytes here too, so the thread shape of k_unpack is kept: BITS/2 dword loads, byte picks at compile-time positions,
+// two 16-B stores; ragged / unaligned groups go sample by sample.
+// ---------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void k_unpack_mipi(const uint8_t* packed, size_t row_stride, uint32_t width,
+                                                     uint32_t rows, uint16_t* out, uint32_t groups_per_row)
+{
+    constexpr int NW = BITS / 2;                   // dwords per 16 samples
+    constexpr int N = BITS == 12 ? 2 : 4;          // pixels per CSI-2 group
+    constexpr int LOW = BITS - 8;                  // low bits per pixel
+    constexpr int GB = N + N * LOW / 8;            // bytes per group
+    constexpr uint32_t LMASK = (1u << LOW) - 1u;
+    const size_t total = (size_t)groups_per_row * rows;
+    const bool aligned = (row_stride & 3u) == 0 && (width & 7u) == 0 && ((size_t)packed & 3u) == 0 && ((size_t)out & 15u) == 0;
+    for (size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (size_t)gridDim.x * 256) {
+        const uint32_t y = (uint32_t)(gi / groups_per_row), g = (uint32_t)(gi - (size_t)y * groups_per_row);
+        const uint8_t* row = packed + (size_t)y * row_stride;
+        uint16_t* orow = out + (size_t)y * width;
+        const uint32_t x0 = g * 16u;
+        if (aligned && x0 + 16u <= width && (size_t)(g + 1) * (2 * BITS) <= row_stride) {
+            uint32_t w[NW];
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(row + (size_t)g * (2 * BITS));
+#pragma unroll
+            for (int k = 0; k < NW; ++k) w[k] = src[k];
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int q = j / N, i = j % N, base = q * GB;
+                const int hb = base + i;                       // the pixel's high byte
+                const int lbit = (base + N) * 8 + i * LOW;     // first of its low bits, as a bit index into the 2*BITS bytes
+                const uint32_t hi = (w[hb >> 2] >> ((hb & 3) * 8)) & 0xffu;
+                const int li = lbit >> 5, ls = lbit & 31;
+                uint32_t lo = w[li] >> ls;
+                if (ls + LOW > 32) lo |= w[li + 1 < NW ? li + 1 : li] << (32 - ls);
+                v[j] = (hi << LOW) | (lo & LMASK);
+            }
+            uint4 a, b;
+            a.x = v[0] | (v[1] << 16); a.y = v[2] | (v[3] << 16); a.z = v[4] | (v[5] << 16); a.w = v[6] | (v[7] << 16);
+            b.x = v[8] | (v[9] << 16); b.y = v[10] | (v[11] << 16); b.z = v[12] | (v[13] << 16); b.w = v[14] | (v[15] << 16);
+            uint4* dst = reinterpret_cast<uint4*>(orow + x0);
+            dst[0] = a; dst[1] = b;
+        } else {
+            for (uint32_t x = x0; x < x0 + 16u && x < width; ++x) {
+                const uint8_t* grp = row + (size_t)(x / N) * GB;
+                const uint32_t i = x % N, bit = i * LOW;
+                uint32_t lo = (uint32_t)grp[N + (bit >> 3)] >> (bit & 7);
+                if ((bit & 7) + LOW > 8) lo |= (uint32_t)grp[N + (bit >> 3) + 1] << (8 - (bit & 7));
+                orow[x] = (uint16_t)(((uint32_t)grp[i] << LOW) | (lo & LMASK));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 template <class K>
@@ -1186,10 +1242,20 @@ hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t wi
 {
     if (width == 0 || rows == 0) return hipSuccess;
     if (!d_packed || !d_out) return hipErrorInvalidValue;
-    if (row_stride < ((size_t)width * bits + 7) / 8 || order > 1u) return hipErrorInvalidValue;
+    if (order > 2u) return hipErrorInvalidValue;
     const uint32_t gpr = (width + 15) / 16;
     const size_t total = (size_t)gpr * rows;
     const uint32_t grid = (uint32_t)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    if (order == 2u) {  // MIPI CSI-2: whole groups of 4 / 2 / 4 pixels in 5 / 3 / 7 bytes
+        if (bits != 10 && bits != 12 && bits != 14) return hipErrorInvalidValue;
+        const uint32_t n = bits == 12 ? 2u : 4u;
+        if (row_stride < (size_t)((width + n - 1) / n) * (n + n * (bits - 8u) / 8u)) return hipErrorInvalidValue;
+        if (bits == 10) hipLaunchKernelGGL((k_unpack_mipi<10>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        else if (bits == 12) hipLaunchKernelGGL((k_unpack_mipi<12>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        else hipLaunchKernelGGL((k_unpack_mipi<14>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
+        return hipGetLastError();
+    }
+    if (row_stride < ((size_t)width * bits + 7) / 8) return hipErrorInvalidValue;
     switch (bits) {
     case 10:
         if (order) hipLaunchKernelGGL((k_unpack<10, true>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);

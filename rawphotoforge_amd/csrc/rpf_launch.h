@@ -45,7 +45,7 @@ hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const Ra
 hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                           const DeviceEdit& ed, void* d_out, int out_format, hipStream_t s);
 // the same with the integer unpack folded in: d_packed holds (rows + 4) bit-packed rows (10/12/14/16 bits), `order` =
-// RPF_PACK_MSB_FIRST (big-endian bit stream) or RPF_PACK_LSB_FIRST (little-endian)
+// RPF_PACK_MSB_FIRST (big-endian bit stream), RPF_PACK_LSB_FIRST (little-endian) or RPF_PACK_MIPI (CSI-2 groups; unpack only)
 hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, uint32_t row_stride, uint32_t bits,
                                  uint32_t order, const RawParamsDev& raw, const TileGeom& g, const DeviceEdit& ed, void* d_out,
                                  int out_format, hipStream_t s);

@@ -423,6 +423,7 @@ def dev_rgb16be_to_rgba_f32(processor: GpuProcessor, d_samples_ptr: int, npix: i
 
 def dev_unpack_bayer(processor: GpuProcessor, d_packed_ptr: int, row_stride: int, width: int, rows: int, bits: int,
                      d_cfa_ptr: int, stream: int = 0, order: int = N.PACK_MSB_FIRST) -> None:
-    """Packed RAW (10/12/14/16-bit, MSB- or LSB-first) -> u16 CFA plane on the device (rpf_dev_unpack_bayer)."""
+    """Packed RAW (10/12/14/16-bit MSB- or LSB-first, or MIPI CSI-2 RAW10/12/14) -> u16 CFA plane on the device
+    (rpf_dev_unpack_bayer)."""
     _check(N.lib().rpf_dev_unpack_bayer(processor._h, C.c_void_p(d_packed_ptr), row_stride, width, rows, bits, order,
                                         C.c_void_p(d_cfa_ptr), C.c_void_p(stream)))

@@ -31,6 +31,43 @@ def test_oracle_known_answers_lsb_first():
             assert np.array_equal((bitsm * (1 << np.arange(bits))).sum(-1), a)
 
 
+def test_oracle_known_answers_mipi():
+    """MIPI CSI-2 RAW10 / RAW12 / RAW14: the byte layouts of the specification's pixel-to-byte packing figures."""
+    M = O.PACK_MIPI
+    # RAW10: P1[9:2] P2[9:2] P3[9:2] P4[9:2] | P4[1:0] P3[1:0] P2[1:0] P1[1:0]
+    px = np.array([[0b1010101001, 0b0000000010, 0b1111111111, 0b0100000000]], np.uint16)
+    by = [0b10101010, 0b00000000, 0b11111111, 0b01000000, 0b00_11_10_01]
+    assert O.pack_bayer(px, 10, order=M)[0, :5].tolist() == by
+    assert O.unpack_bayer(np.array([by + [0, 0, 0]], np.uint8), 4, 10, order=M).tolist() == px.tolist()
+    # RAW12: P1[11:4] P2[11:4] | P2[3:0] P1[3:0]
+    assert O.pack_bayer(np.array([[0xABC, 0xDEF]], np.uint16), 12, order=M)[0, :3].tolist() == [0xAB, 0xDE, 0xFC]
+    assert O.unpack_bayer(np.array([[0xAB, 0xDE, 0xFC, 0]], np.uint8), 2, 12, order=M).tolist() == [[0xABC, 0xDEF]]
+    # RAW14: four high bytes, then P2[1:0] P1[5:0] | P3[3:0] P2[5:2] | P4[5:0] P3[5:4]
+    px = np.array([[(0x81 << 6) | 0b100001, (0x42 << 6) | 0b011110, (0x24 << 6) | 0b110011, (0x18 << 6) | 0b101010]], np.uint16)
+    by = [0x81, 0x42, 0x24, 0x18, 0b10_100001, 0b0011_0111, 0b101010_11]
+    assert O.pack_bayer(px, 14, order=M)[0, :7].tolist() == by
+    assert O.unpack_bayer(np.array([by + [0]], np.uint8), 4, 14, order=M).tolist() == px.tolist()
+    # row sizes: whole groups, then the 4-byte alignment of the packer
+    assert [O.packed_row_stride(w, 10, 1, M) for w in (1, 4, 5, 8)] == [5, 5, 10, 10]
+    assert [O.packed_row_stride(w, 12, 1, M) for w in (1, 2, 3)] == [3, 3, 6]
+    assert [O.packed_row_stride(w, 14, 1, M) for w in (1, 4, 5)] == [7, 7, 14]
+    rng = np.random.default_rng(9)
+    for bits in (10, 12, 14):
+        n = 2 if bits == 12 else 4
+        gb = n + n * (bits - 8) // 8
+        for w in (1, 3, 15, 16, 17, 100, 257):
+            a = rng.integers(0, 1 << bits, (5, w), dtype=np.uint16)
+            p = O.pack_bayer(a, bits, order=M)
+            assert p.shape[1] % 4 == 0 and np.array_equal(O.unpack_bayer(p, w, bits, order=M), a)
+            # numpy cross-check: high bytes, and the low bits as a little-endian bit matrix per group
+            ng = (w + n - 1) // n
+            grp = p[:, :ng * gb].reshape(5, ng, gb)
+            hi = grp[:, :, :n].astype(np.uint16).reshape(5, ng * n)[:, :w]
+            lowm = np.unpackbits(grp[:, :, n:], axis=2, bitorder="little").reshape(5, ng * n, bits - 8)[:, :w]
+            lo = (lowm * (1 << np.arange(bits - 8))).sum(-1)
+            assert np.array_equal((hi << (bits - 8)) | lo, a)
+
+
 @pytest.mark.parametrize("bits", [10, 12, 14, 16])
 def test_oracle_round_trip(bits):
     rng = np.random.default_rng(bits)
@@ -63,6 +100,28 @@ def test_gpu_unpack_bit_exact(gpu, bits, order):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bits", [10, 12, 14])
+def test_gpu_unpack_mipi_bit_exact(gpu, bits):
+    """RPF_PACK_MIPI: the dword fast path (aligned, 16 whole samples) and the per-sample path (ragged widths, widths
+    that end inside a CSI-2 group, odd strides) against the oracle's packer."""
+    torch = pytest.importorskip("torch")
+    import rawphotoforge_amd as R
+    M = O.PACK_MIPI
+    rng = np.random.default_rng(300 + bits)
+    for h, w, extra in ((9, 64, 0), (5, 1000, 0), (4, 37, 0), (3, 16, 4), (6, 6000, 0), (2, 15, 0), (3, 24, 3), (2, 1, 0),
+                        (3, 8, 0)):
+        a = rng.integers(0, 1 << bits, (h, w), dtype=np.uint16)
+        stride = O.packed_row_stride(w, bits, order=M) + extra
+        p = O.pack_bayer(a, bits, stride, order=M)
+        d = torch.from_numpy(p).cuda()
+        out = torch.zeros((h, w), dtype=torch.int16, device="cuda")
+        R.dev_unpack_bayer(gpu, d.data_ptr(), stride, w, h, bits, out.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                           order=M)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), a), (h, w, extra)
+
+
+@pytest.mark.gpu
 def test_gpu_unpack_into_band_buffer_then_develop(gpu):
     """The integer stage feeding the float stages: 12-bit packed -> rows 2.. of a band buffer -> fused kernel."""
     torch = pytest.importorskip("torch")
@@ -89,6 +148,12 @@ def test_gpu_unpack_rejects_bad_arguments(gpu):
         R.dev_unpack_bayer(gpu, 1, 64, 16, 1, 11, 1)       # unsupported bit depth
     with pytest.raises(R.InvalidArgument):
         R.dev_unpack_bayer(gpu, 1, 8, 16, 1, 12, 1)        # stride shorter than a row
+    with pytest.raises(R.PhotoEditorError):
+        R.dev_unpack_bayer(gpu, 1, 64, 16, 1, 16, 1, order=R.PACK_MIPI)   # CSI-2 has no packed RAW16 layout here
+    with pytest.raises(R.InvalidArgument):
+        R.dev_unpack_bayer(gpu, 1, 21, 17, 1, 10, 1, order=R.PACK_MIPI)   # 17 px = 5 groups = 25 B
+    with pytest.raises(R.InvalidArgument):
+        R.dev_unpack_bayer(gpu, 1, 64, 16, 1, 12, 1, order=3)             # unknown order
 
 
 @pytest.mark.gpu
