@@ -532,6 +532,46 @@ def test_editors_share_a_processor_and_interleave(gpu):
             assert_parity(ed.rgba(), O.apply(rgba, [p]))
 
 
+def test_processor_shared_by_threads(gpu):
+    """SURVEY 8(b) threading: an editor is externally synchronised, the processor is safe to share.  Four threads, each
+    with its own editors (an RGB one and a Bayer one) on the ONE processor, create / configure / apply / read back
+    concurrently (ctypes drops the GIL inside every call); every result is compared with the oracle, bit for bit, and
+    an error on one thread (unknown mask name) leaves its message on that thread only."""
+    import threading
+
+    def worker(i, failures):
+        try:
+            rng = np.random.default_rng(1000 + i)
+            h, w = 48 + 8 * i, 80 + 16 * i
+            img = rng.random((h, w, 3), dtype=np.float32)
+            rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+            cfa = rng.integers(0, 16384, (h, w), dtype=np.uint16)
+            rp = O.RawParams(cfa_pattern=i % 4, black=(512,) * 4, white=16383, wb=(2.0, 1.0, 1.0, 1.5))
+            for rep in range(6):
+                ed_rgb = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+                ed_raw = bayer_editor(gpu, cfa, rp)
+                p, q = util.random_params(rng), util.random_params(rng)
+                util.configure_editor(ed_rgb, p)
+                util.configure_editor(ed_raw, q)
+                ed_rgb.apply_adjustments()
+                ed_raw.apply_adjustments()
+                with pytest.raises(R.MaskNotFound) as ei:
+                    ed_rgb.set_whitebalance(1, 1, f"no such mask {i}")
+                assert f"no such mask {i}" in str(ei.value)
+                assert_parity(ed_rgb.rgba(), O.apply(rgba, [p]))
+                assert_parity(ed_raw.rgba(), O.develop(cfa, rp, [q]))
+        except BaseException as e:  # noqa: BLE001 - reported on the main thread
+            failures.append((i, repr(e)))
+
+    failures = []
+    threads = [threading.Thread(target=worker, args=(i, failures)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
+
+
 def test_incremental_setter_traffic(gpu):
     """Per-curve dirty tracking: after each small change (one curve, one slider, the same control points again, the
     same full curve again, a mask added / removed, reset) the next apply must equal the oracle on the full state."""
