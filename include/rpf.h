@@ -130,6 +130,16 @@ int rpf_processor_compute_units(const rpf_processor* p, int* cus);
  * follows the wasm order). */
 int rpf_editor_create_from_rgb_f32(rpf_processor* p, const float* rgb, uint32_t width, uint32_t height,
                                    rpf_editor** out);
+/* Decoded 8- / 16-bit interleaved RGB, what read_image holds behind the decoder (rust/photo-editor/src/image.rs:412-447):
+ * to_rgb32f (:443) is v / 255 resp. v / 65535 — one binary32 division — and the upload pads alpha = 1 (:135-139); both
+ * happen on the device here.  lut (256 resp. 65536 floats, or NULL): applied INSTEAD of the quotient, out = lut[v].  It is
+ * how the caller renders the step between decode and conversion, apply_color_space(SRGB_LINEAR) for JPEG / PNG / WebP
+ * (:431-441), whose arithmetic is inside image 0.25.10 / moxcms 0.8.1 and not in the reference tree (NULL = the TIFF
+ * branch, :432).  An empty image gives RPF_ERR_FAILED_TO_READ_IMAGE. */
+int rpf_editor_create_from_rgb_u8(rpf_processor* p, const uint8_t* rgb, uint32_t width, uint32_t height,
+                                  const float* lut256, rpf_editor** out);
+int rpf_editor_create_from_rgb_u16(rpf_processor* p, const uint16_t* rgb, uint32_t width, uint32_t height,
+                                   const float* lut65536, rpf_editor** out);
 /* u16 Bayer plane, pitch = width.  The editor keeps the CFA on the device; apply runs the
  * fused demosaic -> ... -> gamma kernel. */
 int rpf_editor_create_from_bayer_u16(rpf_processor* p, const uint16_t* cfa, uint32_t width, uint32_t height,
@@ -233,6 +243,12 @@ int rpf_dev_prefetch(rpf_processor* p, const void* d_buf, size_t bytes, void* st
 enum { RPF_PACK_MSB_FIRST = 0, RPF_PACK_LSB_FIRST = 1, RPF_PACK_MIPI = 2 };
 int rpf_dev_unpack_bayer(rpf_processor* p, const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows,
                          uint32_t bits, uint32_t order, uint16_t* d_cfa_out, void* stream);
+/* npix decoded RGB triplets -> RGBA32F on the device: v / 255 resp. v / 65535 (image.rs:443), or d_lut[v] when a table
+ * (256 resp. 65536 floats in device memory) is given; alpha 1.  See rpf_editor_create_from_rgb_u8. */
+int rpf_dev_rgb_u8_to_rgba_f32(rpf_processor* p, const uint8_t* d_rgb, size_t npix, const float* d_lut256,
+                               float* d_rgba_out, void* stream);
+int rpf_dev_rgb_u16_to_rgba_f32(rpf_processor* p, const uint16_t* d_rgb, size_t npix, const float* d_lut65536,
+                                float* d_rgba_out, void* stream);
 /* npix big-endian 16-bit RGB triplets (2-byte aligned) -> RGBA32F, v / 65535, alpha 1 (image.ts:172-189) */
 int rpf_dev_rgb16be_to_rgba_f32(rpf_processor* p, const uint8_t* d_rgb16be, size_t npix, float* d_rgba_out,
                                 void* stream);

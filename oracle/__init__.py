@@ -346,6 +346,25 @@ def resize_long_edge(img, target: int) -> np.ndarray:
     return out
 
 
+def rgb_int_to_rgba(img, lut=None) -> np.ndarray:
+    """image.rs:443 to_rgb32f (+ alpha 1) of a decoded (H, W, 3) uint8 / uint16 image; `lut` (256 / 65536 floats)
+    replaces the v / MAX quotient (the caller's colour-space step, image.rs:431-441)."""
+    a = np.ascontiguousarray(img)
+    if a.dtype not in (np.uint8, np.uint16) or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("expected (H, W, 3) uint8 or uint16")
+    n = 256 if a.dtype == np.uint8 else 65536
+    t = None
+    if lut is not None:
+        t = np.ascontiguousarray(lut, np.float32)
+        if t.size != n:
+            raise ValueError(f"lut must hold {n} floats")
+    out = np.empty(a.shape[:2] + (4,), np.float32)
+    fn = lib().orc_rgb_u8_to_rgba if a.dtype == np.uint8 else lib().orc_rgb_u16_to_rgba
+    fn(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.shape[0] * a.shape[1]),
+       t.ctypes.data_as(C.c_void_p) if t is not None else None, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def ppm16_header(file_bytes):
     """web-ts/core/image.ts:146-173 -> (status, width, height, data_offset); status 0 ok, 1 not P6, 2 size line,
     3 maxval, 4 truncated."""

@@ -10,6 +10,6 @@ from .editor import (EmptyControlPoints, FailedToReadImage, GpuComputeError, Gpu
                      InterpolationError, InvalidArgument, InvalidCurveLength, MaskNotFound, MismatchedLengths,
                      MissingControlPoints, MissingCurveOrControlPoints, NotEnoughPoints, NotStrictlyIncreasing,
                      PhotoEditor, PhotoEditorError, RawParams, TooManyMasks, dev_demosaic, dev_rgb16be_to_rgba_f32,
-                     dev_prefetch, dev_unpack_bayer, pchip_interpolate, ppm16_parse_header)
+                     dev_prefetch, dev_rgb_int_to_rgba_f32, dev_unpack_bayer, pchip_interpolate, ppm16_parse_header)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -71,6 +71,8 @@ SYMBOLS = {
     "rpf_editor_create_from_rgb_f32": (C.c_int, [_vp, _f32p, C.c_uint32, C.c_uint32, _P(_vp)]),
     "rpf_editor_create_from_bayer_u16": (C.c_int, [_vp, _P(C.c_uint16), C.c_uint32, C.c_uint32, _P(RawParams),
                                                    _P(_vp)]),
+    "rpf_editor_create_from_rgb_u8": (C.c_int, [_vp, _P(C.c_uint8), C.c_uint32, C.c_uint32, _f32p, _P(_vp)]),
+    "rpf_editor_create_from_rgb_u16": (C.c_int, [_vp, _P(C.c_uint16), C.c_uint32, C.c_uint32, _f32p, _P(_vp)]),
     "rpf_ppm16_parse_header": (C.c_int, [_P(C.c_uint8), _sz, _P(C.c_uint32), _P(C.c_uint32), _P(_sz)]),
     "rpf_editor_create_from_ppm16": (C.c_int, [_vp, _P(C.c_uint8), _sz, _P(_vp)]),
     "rpf_editor_create_headless": (C.c_int, [C.c_uint32, C.c_uint32, _P(_vp)]),
@@ -104,6 +106,8 @@ SYMBOLS = {
     "rpf_pchip_interpolate_i32": (C.c_int, [_i32p, _sz, _i32p, _sz, _i32p, _sz, _i32p, _i32p]),
     "rpf_dev_prefetch": (C.c_int, [_vp, _vp, _sz, _vp]),
     "rpf_dev_unpack_bayer": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "rpf_dev_rgb_u8_to_rgba_f32": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "rpf_dev_rgb_u16_to_rgba_f32": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "rpf_dev_rgb16be_to_rgba_f32": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "rpf_dev_demosaic": (C.c_int, [_vp, _vp, _P(RawParams), _P(Tile), _vp, _vp]),
     "rpf_dev_develop": (C.c_int, [_vp, _vp, _P(RawParams), _vp, C.c_int, _vp]),

@@ -483,6 +483,50 @@ int rpf_editor_create_from_ppm16(rpf_processor* p, const uint8_t* file, size_t l
     return ok();
 }
 
+// decoded 8- / 16-bit RGB -> editor (image.rs:412-447 behind the decoder): staged, converted on the device
+static int create_from_rgb_int(rpf_processor* p, const void* rgb, int bits, uint32_t width, uint32_t height,
+                               const float* lut, rpf_editor** out)
+{
+    if (!p || !out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (!rgb || width == 0 || height == 0)
+        return fail(RPF_ERR_FAILED_TO_READ_IMAGE, "Failed to read image: empty image");
+    rpf_tile t{width, height, 0, height};
+    rpf_editor* e = nullptr;
+    int rc = rpf_editor_create_for_tile(p, &t, &e);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height, in_bytes = npix * 3 * (size_t)(bits / 8);
+    const size_t lut_bytes = lut ? sizeof(float) * ((size_t)1 << bits) : 0;
+    uint8_t* d_raw = nullptr;
+    float* d_lut = nullptr;
+    hipError_t he = hipMalloc((void**)&d_raw, in_bytes);
+    if (he == hipSuccess && lut) he = hipMalloc((void**)&d_lut, lut_bytes);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->d_original, npix * 4 * sizeof(float));
+    if (he == hipSuccess) he = hipMemcpy(d_raw, rgb, in_bytes, hipMemcpyHostToDevice);
+    if (he == hipSuccess && lut) he = hipMemcpy(d_lut, lut, lut_bytes, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = launch_rgb_int(d_raw, bits, npix, d_lut, e->d_original, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (d_raw) (void)hipFree(d_raw);
+    if (d_lut) (void)hipFree(d_lut);
+    if (he != hipSuccess) { rpf_editor_destroy(e); return hip_fail(he, "upload decoded image"); }
+    e->original_valid = true;
+    e->owns_image = true;
+    *out = e;
+    return ok();
+}
+
+int rpf_editor_create_from_rgb_u8(rpf_processor* p, const uint8_t* rgb, uint32_t width, uint32_t height,
+                                  const float* lut256, rpf_editor** out)
+{
+    return create_from_rgb_int(p, rgb, 8, width, height, lut256, out);
+}
+
+int rpf_editor_create_from_rgb_u16(rpf_processor* p, const uint16_t* rgb, uint32_t width, uint32_t height,
+                                   const float* lut65536, rpf_editor** out)
+{
+    return create_from_rgb_int(p, rgb, 16, width, height, lut65536, out);
+}
+
 int rpf_editor_create_from_bayer_u16(rpf_processor* p, const uint16_t* cfa, uint32_t width, uint32_t height,
                                      const rpf_raw_params* raw, rpf_editor** out)
 {
@@ -786,6 +830,25 @@ int rpf_dev_prefetch(rpf_processor* p, const void* d_buf, size_t bytes, void* st
     if (!p || (!d_buf && bytes)) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(launch_touch(d_buf, bytes, p->num_cus, (hipStream_t)stream));
+    return ok();
+}
+
+int rpf_dev_rgb_u8_to_rgba_f32(rpf_processor* p, const uint8_t* d_rgb, size_t npix, const float* d_lut256, float* d_rgba_out,
+                               void* stream)
+{
+    if (!p || !d_rgb || !d_rgba_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(launch_rgb_int(d_rgb, 8, npix, d_lut256, d_rgba_out, (hipStream_t)stream));
+    return ok();
+}
+
+int rpf_dev_rgb_u16_to_rgba_f32(rpf_processor* p, const uint16_t* d_rgb, size_t npix, const float* d_lut65536,
+                                float* d_rgba_out, void* stream)
+{
+    if (!p || !d_rgb || !d_rgba_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (reinterpret_cast<uintptr_t>(d_rgb) & 1) return fail(RPF_ERR_INVALID_ARGUMENT, "samples must be 2-byte aligned");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(launch_rgb_int(d_rgb, 16, npix, d_lut65536, d_rgba_out, (hipStream_t)stream));
     return ok();
 }
 

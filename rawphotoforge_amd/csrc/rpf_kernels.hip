@@ -749,6 +749,28 @@ __global__ __launch_bounds__(256) void k_rgb16be(const uint16_t* in, size_t npix
 }
 
 // ---------------------------------------------------------------------------
+// k_rgb_int — decoded 8- / 16-bit interleaved RGB -> RGBA32F (image.rs:443 to_rgb32f + the alpha pad of :135-139):
+// v / 255 or v / 65535, one IEEE binary32 division, or lut[v] when the caller supplies the colour-space step as a
+// table.  One pixel per lane: three narrow loads that the wavefront covers with 192 / 384 contiguous bytes, one 16-B
+// store; 19 / 22 B of HBM traffic per pixel bound it, not the instruction count.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_rgb_int(const T* in, size_t npix, const float* lut, float4* out)
+{
+    constexpr float MAXV = sizeof(T) == 1 ? 255.0f : 65535.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const uint32_t r = in[i * 3], g = in[i * 3 + 1], b = in[i * 3 + 2];
+        float4 o;
+        if (lut) {  // kernel-uniform
+            o = make_float4(lut[r], lut[g], lut[b], 1.0f);
+        } else {
+            o = make_float4((float)r / MAXV, (float)g / MAXV, (float)b / MAXV, 1.0f);  // correctly rounded (hipcc default)
+        }
+        out[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_resize — the preview pyramid's bilinear resize (web/main.ts:958-1026 resizeFloat32RGBLongEdge),
 // RGBA32F -> RGBA32F on the device, binary64 arithmetic in the JavaScript source order, one thread
 // per destination pixel.  Alpha is rewritten as 1.
@@ -1333,6 +1355,21 @@ hipError_t launch_pad_rgb(const float* d_rgb, size_t npix, float* d_rgba, hipStr
     if (!d_rgb || !d_rgba) return hipErrorInvalidValue;
     const uint32_t grid = (uint32_t)((npix + 255) / 256 > 4096 ? 4096 : (npix + 255) / 256);
     hipLaunchKernelGGL(k_pad_rgb, dim3(grid), dim3(256), 0, s, d_rgb, npix, reinterpret_cast<float4*>(d_rgba));
+    return hipGetLastError();
+}
+
+hipError_t launch_rgb_int(const void* d_in, int bits, size_t npix, const float* d_lut, float* d_rgba, hipStream_t s)
+{
+    if (npix == 0) return hipSuccess;
+    if (!d_in || !d_rgba || (bits != 8 && bits != 16)) return hipErrorInvalidValue;
+    if (bits == 16 && (reinterpret_cast<uintptr_t>(d_in) & 1)) return hipErrorInvalidValue;
+    const uint32_t grid = (uint32_t)((npix + 255) / 256 > 16384 ? 16384 : (npix + 255) / 256);
+    if (bits == 8)
+        hipLaunchKernelGGL((k_rgb_int<uint8_t>), dim3(grid), dim3(256), 0, s, static_cast<const uint8_t*>(d_in), npix, d_lut,
+                           reinterpret_cast<float4*>(d_rgba));
+    else
+        hipLaunchKernelGGL((k_rgb_int<uint16_t>), dim3(grid), dim3(256), 0, s, static_cast<const uint16_t*>(d_in), npix, d_lut,
+                           reinterpret_cast<float4*>(d_rgba));
     return hipGetLastError();
 }
 

@@ -65,6 +65,8 @@ hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_
 hipError_t launch_combine_masks(const uint8_t* d_planes, uint32_t planes, size_t npix, uint16_t* d_bits, hipStream_t s);
 // interleaved RGB f32 -> RGBA32F, alpha = 1 (image.rs:135-139)
 hipError_t launch_pad_rgb(const float* d_rgb, size_t npix, float* d_rgba, hipStream_t s);
+// decoded 8- / 16-bit interleaved RGB -> RGBA32F: v / 255, v / 65535, or d_lut[v] (256 / 65536 floats on the device)
+hipError_t launch_rgb_int(const void* d_in, int bits, size_t npix, const float* d_lut, float* d_rgba, hipStream_t s);
 hipError_t launch_rgb16be(const uint8_t* d_in, size_t npix, float* d_rgba, hipStream_t s);
 
 }  // namespace rpf

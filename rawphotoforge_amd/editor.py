@@ -202,6 +202,25 @@ class PhotoEditor:
         return cls(h, gpu_processor)
 
     @classmethod
+    def new_from_rgb_int(cls, gpu_processor: GpuProcessor, image, lut=None) -> "PhotoEditor":
+        """A decoded (H, W, 3) uint8 / uint16 image (read_image behind the decoder, image.rs:412-447): v / 255 resp.
+        v / 65535 on the device, or lut[v] (256 / 65536 floats: the caller's colour-space step, image.rs:431-441)."""
+        a = np.ascontiguousarray(image)
+        if a.dtype not in (np.uint8, np.uint16) or a.ndim != 3 or a.shape[2] != 3:
+            raise FailedToReadImage("Failed to read image: expected (H, W, 3) uint8 or uint16")
+        wide = a.dtype == np.uint16
+        t = None
+        if lut is not None:
+            t = np.ascontiguousarray(lut, dtype=np.float32).reshape(-1)
+            if t.size != (65536 if wide else 256):
+                raise InvalidArgument("the table must hold one float per sample value")
+        h = C.c_void_p()
+        fn = N.lib().rpf_editor_create_from_rgb_u16 if wide else N.lib().rpf_editor_create_from_rgb_u8
+        _check(fn(gpu_processor._h, _ptr(a, C.c_uint16 if wide else C.c_uint8), a.shape[1], a.shape[0],
+                  _ptr(t, C.c_float) if t is not None else None, C.byref(h)))
+        return cls(h, gpu_processor)
+
+    @classmethod
     def new_from_ppm16(cls, gpu_processor: GpuProcessor, file_bytes) -> "PhotoEditor":
         """A 16-bit P6 PPM file (web-ts/core/image.ts:146-195 loadPpm); samples become f32 on the device."""
         a = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
@@ -413,6 +432,16 @@ def ppm16_parse_header(file_bytes):
     w, h, off = C.c_uint32(), C.c_uint32(), C.c_size_t()
     _check(N.lib().rpf_ppm16_parse_header(_ptr(a, C.c_uint8), a.size, C.byref(w), C.byref(h), C.byref(off)))
     return w.value, h.value, off.value
+
+
+def dev_rgb_int_to_rgba_f32(processor: GpuProcessor, d_samples_ptr: int, bits: int, npix: int, d_rgba_ptr: int,
+                            d_lut_ptr: int = 0, stream: int = 0) -> None:
+    """Decoded 8- / 16-bit RGB triplets in device memory -> RGBA32F (rpf_dev_rgb_u8 / _u16_to_rgba_f32)."""
+    if bits not in (8, 16):
+        raise InvalidArgument("bits must be 8 or 16")
+    fn = N.lib().rpf_dev_rgb_u8_to_rgba_f32 if bits == 8 else N.lib().rpf_dev_rgb_u16_to_rgba_f32
+    _check(fn(processor._h, C.c_void_p(d_samples_ptr), npix, C.c_void_p(d_lut_ptr or None), C.c_void_p(d_rgba_ptr),
+              C.c_void_p(stream)))
 
 
 def dev_rgb16be_to_rgba_f32(processor: GpuProcessor, d_samples_ptr: int, npix: int, d_rgba_ptr: int, stream: int = 0) -> None:

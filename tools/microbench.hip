@@ -100,6 +100,26 @@ F32_KERNEL(k_sub_f32_lit, "v_sub_f32 %0, 0x3f9e3779, %0", "v_sub_f32 %1, 0x3f9e3
 F32_KERNEL(k_fmac_f32, "v_fmac_f32 %0, %8, %9", "v_fmac_f32 %1, %8, %9", "v_fmac_f32 %2, %8, %9", "v_fmac_f32 %3, %8, %9", "v_fmac_f32 %4, %8, %9", "v_fmac_f32 %5, %8, %9", "v_fmac_f32 %6, %8, %9", "v_fmac_f32 %7, %8, %9")
 F32_KERNEL(k_mad_lit, "v_fmaak_f32 %0, %8, %0, 0x3f9e3779", "v_fmaak_f32 %1, %8, %1, 0x3f9e3779", "v_fmaak_f32 %2, %8, %2, 0x3f9e3779", "v_fmaak_f32 %3, %8, %3, 0x3f9e3779", "v_fmaak_f32 %4, %8, %4, 0x3f9e3779", "v_fmaak_f32 %5, %8, %5, 0x3f9e3779", "v_fmaak_f32 %6, %8, %6, 0x3f9e3779", "v_fmaak_f32 %7, %8, %7, 0x3f9e3779")
 
+F32_KERNEL(k_bfi_b32, "v_bfi_b32 %0, %8, %9, %0", "v_bfi_b32 %1, %8, %9, %1", "v_bfi_b32 %2, %8, %9, %2", "v_bfi_b32 %3, %8, %9, %3", "v_bfi_b32 %4, %8, %9, %4", "v_bfi_b32 %5, %8, %9, %5", "v_bfi_b32 %6, %8, %9, %6", "v_bfi_b32 %7, %8, %9, %7")
+F32_KERNEL(k_xor_b32, "v_xor_b32 %0, %8, %0", "v_xor_b32 %1, %8, %1", "v_xor_b32 %2, %8, %2", "v_xor_b32 %3, %8, %3", "v_xor_b32 %4, %8, %4", "v_xor_b32 %5, %8, %5", "v_xor_b32 %6, %8, %6", "v_xor_b32 %7, %8, %7")
+F32_KERNEL(k_perm_b32, "v_perm_b32 %0, %0, %8, %9", "v_perm_b32 %1, %1, %8, %9", "v_perm_b32 %2, %2, %8, %9", "v_perm_b32 %3, %3, %8, %9", "v_perm_b32 %4, %4, %8, %9", "v_perm_b32 %5, %5, %8, %9", "v_perm_b32 %6, %6, %8, %9", "v_perm_b32 %7, %7, %8, %9")
+F32_KERNEL(k_add_f32_dpp, "v_add_f32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_f32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_f32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_f32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_f32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_f32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_f32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_f32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf")
+F32_KERNEL(k_add_f32_clamp, "v_add_f32_e64 %0, %8, %0 clamp", "v_add_f32_e64 %1, %8, %1 clamp", "v_add_f32_e64 %2, %8, %2 clamp", "v_add_f32_e64 %3, %8, %3 clamp", "v_add_f32_e64 %4, %8, %4 clamp", "v_add_f32_e64 %5, %8, %5 clamp", "v_add_f32_e64 %6, %8, %6 clamp", "v_add_f32_e64 %7, %8, %7 clamp")
+F32_KERNEL(k_mul_f32_neg, "v_mul_f32_e64 %0, -%8, %0", "v_mul_f32_e64 %1, -%8, %1", "v_mul_f32_e64 %2, -%8, %2", "v_mul_f32_e64 %3, -%8, %3", "v_mul_f32_e64 %4, -%8, %4", "v_mul_f32_e64 %5, -%8, %5", "v_mul_f32_e64 %6, -%8, %6", "v_mul_f32_e64 %7, -%8, %7")
+F32_KERNEL(k_max_u32, "v_max_u32 %0, %8, %0", "v_max_u32 %1, %8, %1", "v_max_u32 %2, %8, %2", "v_max_u32 %3, %8, %3", "v_max_u32 %4, %8, %4", "v_max_u32 %5, %8, %5", "v_max_u32 %6, %8, %6", "v_max_u32 %7, %8, %7")
+F32_KERNEL(k_max_i32, "v_max_i32 %0, %8, %0", "v_max_i32 %1, %8, %1", "v_max_i32 %2, %8, %2", "v_max_i32 %3, %8, %3", "v_max_i32 %4, %8, %4", "v_max_i32 %5, %8, %5", "v_max_i32 %6, %8, %6", "v_max_i32 %7, %8, %7")
+F32_KERNEL(k_sub_u32, "v_sub_u32 %0, %8, %0", "v_sub_u32 %1, %8, %1", "v_sub_u32 %2, %8, %2", "v_sub_u32 %3, %8, %3", "v_sub_u32 %4, %8, %4", "v_sub_u32 %5, %8, %5", "v_sub_u32 %6, %8, %6", "v_sub_u32 %7, %8, %7")
+F32_KERNEL(k_add3_u32, "v_add3_u32 %0, %0, %8, %9", "v_add3_u32 %1, %1, %8, %9", "v_add3_u32 %2, %2, %8, %9", "v_add3_u32 %3, %3, %8, %9", "v_add3_u32 %4, %4, %8, %9", "v_add3_u32 %5, %5, %8, %9", "v_add3_u32 %6, %6, %8, %9", "v_add3_u32 %7, %7, %8, %9")
+F32_KERNEL(k_alignbit, "v_alignbit_b32 %0, %0, %8, 7", "v_alignbit_b32 %1, %1, %8, 7", "v_alignbit_b32 %2, %2, %8, 7", "v_alignbit_b32 %3, %3, %8, 7", "v_alignbit_b32 %4, %4, %8, 7", "v_alignbit_b32 %5, %5, %8, 7", "v_alignbit_b32 %6, %6, %8, 7", "v_alignbit_b32 %7, %7, %8, 7")
+F32_KERNEL(k_ldexp_f32, "v_ldexp_f32 %0, %0, 1", "v_ldexp_f32 %1, %1, 1", "v_ldexp_f32 %2, %2, 1", "v_ldexp_f32 %3, %3, 1", "v_ldexp_f32 %4, %4, 1", "v_ldexp_f32 %5, %5, 1", "v_ldexp_f32 %6, %6, 1", "v_ldexp_f32 %7, %7, 1")
+F32_KERNEL(k_mul_u32_u24, "v_mul_u32_u24 %0, %8, %0", "v_mul_u32_u24 %1, %8, %1", "v_mul_u32_u24 %2, %8, %2", "v_mul_u32_u24 %3, %8, %3", "v_mul_u32_u24 %4, %8, %4", "v_mul_u32_u24 %5, %8, %5", "v_mul_u32_u24 %6, %8, %6", "v_mul_u32_u24 %7, %8, %7")
+F32_KERNEL(k_or3, "v_or3_b32 %0, %0, %8, %9", "v_or3_b32 %1, %1, %8, %9", "v_or3_b32 %2, %2, %8, %9", "v_or3_b32 %3, %3, %8, %9", "v_or3_b32 %4, %4, %8, %9", "v_or3_b32 %5, %5, %8, %9", "v_or3_b32 %6, %6, %8, %9", "v_or3_b32 %7, %7, %8, %9")
+F32_KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 3, %8", "v_lshl_or_b32 %1, %1, 3, %8", "v_lshl_or_b32 %2, %2, 3, %8", "v_lshl_or_b32 %3, %3, 3, %8", "v_lshl_or_b32 %4, %4, 3, %8", "v_lshl_or_b32 %5, %5, 3, %8", "v_lshl_or_b32 %6, %6, 3, %8", "v_lshl_or_b32 %7, %7, 3, %8")
+F32_KERNEL(k_fma_f32_neg, "v_fma_f32 %0, -%8, %9, %0", "v_fma_f32 %1, -%8, %9, %1", "v_fma_f32 %2, -%8, %9, %2", "v_fma_f32 %3, -%8, %9, %3", "v_fma_f32 %4, -%8, %9, %4", "v_fma_f32 %5, -%8, %9, %5", "v_fma_f32 %6, -%8, %9, %6", "v_fma_f32 %7, -%8, %9, %7")
+F32_KERNEL(k_cvt_ubyte, "v_cvt_f32_ubyte0 %0, %0", "v_cvt_f32_ubyte0 %1, %1", "v_cvt_f32_ubyte0 %2, %2", "v_cvt_f32_ubyte0 %3, %3", "v_cvt_f32_ubyte0 %4, %4", "v_cvt_f32_ubyte0 %5, %5", "v_cvt_f32_ubyte0 %6, %6", "v_cvt_f32_ubyte0 %7, %7")
+F32_KERNEL(k_floor_f32, "v_floor_f32 %0, %0", "v_floor_f32 %1, %1", "v_floor_f32 %2, %2", "v_floor_f32 %3, %3", "v_floor_f32 %4, %4", "v_floor_f32 %5, %5", "v_floor_f32 %6, %6", "v_floor_f32 %7, %7")
+F32_KERNEL(k_frexp_mant, "v_frexp_mant_f32 %0, %0", "v_frexp_mant_f32 %1, %1", "v_frexp_mant_f32 %2, %2", "v_frexp_mant_f32 %3, %3", "v_frexp_mant_f32 %4, %4", "v_frexp_mant_f32 %5, %5", "v_frexp_mant_f32 %6, %6", "v_frexp_mant_f32 %7, %7")
+
 // 64-bit operand kernels: accumulators are doubles / float2
 #define F64_KERNEL(NAME, T, INIT, I0, I1, I2, I3, I4, I5, I6, I7)                                           \
     __global__ void NAME(float* out, long long* cyc, T x, T y)                                               \
@@ -248,6 +268,28 @@ int main(int argc, char**)
     (void)hipMemcpy(hclk, dclk, 24, hipMemcpyDeviceToHost);
     printf("s_memtime ticks per s_memrealtime tick (100 MHz): %.3f -> s_memtime at %.1f MHz\n", (double)hclk[0] / hclk[1], 100.0 * hclk[0] / hclk[1]);
     printf("per wave-instruction per SIMD: s_memtime ticks | wall ns, at waves/SIMD = 1, 2, 4, 8\n");
+    if (argc > 2) {   // third batch (r02): candidates for replacing half-rate selects / shuffles
+        run("v_bfi_b32", k_bfi_b32, 0, 1.0001f, 0.5f);
+        run("v_xor_b32", k_xor_b32, 0, 1.0001f, 0.5f);
+        run("v_perm_b32", k_perm_b32, 0, 1.0001f, 0.5f);
+        run("v_add_f32 dpp", k_add_f32_dpp, 0, 1.0001f, 0.5f);
+        run("v_add_f32 clamp", k_add_f32_clamp, 0, 1.0001f, 0.5f);
+        run("v_mul_f32 neg", k_mul_f32_neg, 0, 1.0001f, 0.5f);
+        run("v_fma_f32 neg", k_fma_f32_neg, 0, 1.0001f, 0.5f);
+        run("v_max_u32", k_max_u32, 0, 1.0001f, 0.5f);
+        run("v_max_i32", k_max_i32, 0, 1.0001f, 0.5f);
+        run("v_sub_u32", k_sub_u32, 0, 1.0001f, 0.5f);
+        run("v_add3_u32", k_add3_u32, 0, 1.0001f, 0.5f);
+        run("v_alignbit_b32", k_alignbit, 0, 1.0001f, 0.5f);
+        run("v_ldexp_f32", k_ldexp_f32, 0, 1.0001f, 0.5f);
+        run("v_mul_u32_u24", k_mul_u32_u24, 0, 1.0001f, 0.5f);
+        run("v_or3_b32", k_or3, 0, 1.0001f, 0.5f);
+        run("v_lshl_or_b32", k_lshl_or, 0, 1.0001f, 0.5f);
+        run("v_cvt_f32_ubyte0", k_cvt_ubyte, 0, 1.0001f, 0.5f);
+        run("v_floor_f32", k_floor_f32, 0, 1.0001f, 0.5f);
+        run("v_frexp_mant_f32", k_frexp_mant, 0, 1.0001f, 0.5f);
+        return 0;
+    }
     if (argc > 1) {   // second batch (r01 late): forms of select / compare, a few more classes
         run("cnd e32 vcc", k_cnd_e32, 0, 1.0001f, 0.5f);
         run("cnd e64 vcc", k_cnd_e64vcc, 0, 1.0001f, 0.5f);
