@@ -60,6 +60,8 @@ def main():
                          "share ONE GPU (RCCL refuses that) to rehearse the N > 1 code path — its timings mean nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos, then one launch per band")
+    ap.add_argument("--pack", default="msb", choices=["msb", "mipi"],
+                    help="develop_packed: 14-bit MSB-first bit stream (default) or MIPI CSI-2 RAW14 groups")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="--workload batch: skip the streaming read (rpf_dev_prefetch) in front of every frame")
     ap.add_argument("--event-stride", type=int, default=4,
@@ -142,11 +144,12 @@ def main():
         packed = torch.from_numpy(syn.pack_msb(cfa & 0x0FFF, 12)).cuda()
     packed_band, packed_stride = None, 0
     if args.workload == "develop_packed":   # the same frame as "develop" (14-bit values), bit-packed incl. halo rows
-        host_packed = syn.pack_msb(band.cpu().numpy().view(np.uint16), 14)
+        host_packed = (syn.pack_mipi if args.pack == "mipi" else syn.pack_msb)(band.cpu().numpy().view(np.uint16), 14)
         packed_stride = host_packed.shape[1]
         packed_band = torch.from_numpy(host_packed).cuda()
         dev_packed = tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, configure, rank, world,
-                                         overlap=not args.no_overlap, packed=(14, packed_stride, R.PACK_MSB_FIRST))
+                                         overlap=not args.no_overlap,
+                                         packed=(14, packed_stride, R.PACK_MIPI if args.pack == "mipi" else R.PACK_MSB_FIRST))
     stream = torch.cuda.current_stream().cuda_stream
     stride_ev = max(1, args.event_stride)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % stride_ev == 0 else None
@@ -225,6 +228,8 @@ def main():
                          f"data ({args.data}), "
                          + (f"batch of {world * len(pool)} different frames, {len(pool)} per GPU, one frame per GPU per step "
                             f"(replicas, no exchange)" if batch else f"frame {W}x{frame_h} in {world} row band(s)")
+                         + (f", input 14-bit {'MIPI CSI-2 RAW14 groups' if args.pack == 'mipi' else 'MSB-first bit stream'}"
+                            if args.workload == "develop_packed" else "")
                          + (f", {args.masks} masks" if args.masks > 1 else "")
                          + (", REHEARSAL over gloo: ranks may share a GPU, timings are not a measurement"
                             if world > 1 and args.backend != "nccl" else "")

@@ -236,8 +236,8 @@ int rpf_dev_prefetch(rpf_processor* p, const void* d_buf, size_t bytes, void* st
  * RPF_PACK_LSB_FIRST: the same bit positions counted from the least significant bit of byte 0, least significant
  * sample bit first (the row read as one little-endian integer);
  * RPF_PACK_MIPI: MIPI CSI-2 RAW10 / RAW12 / RAW14 — groups of 4 / 2 / 4 pixels in 5 / 3 / 7 bytes, the pixels' high
- * bytes first, then their bits - 8 low bits LSB-first in pixel order; a row holds whole groups (bits 16 is refused,
- * and so is this order by rpf_dev_develop_packed: unpack, then rpf_dev_develop).  Rows start every row_stride bytes.
+ * bytes first, then their bits - 8 low bits LSB-first in pixel order; a row holds whole groups (bits 16 is refused).
+ * Rows start every row_stride bytes.
  * bits in {10, 12, 14, 16}.  d_cfa_out has pitch `width` (write it at row 2 of a band buffer).  In the reference
  * this step is inside rawler / LibRaw (rust-godot-legacy/photo-editor/src/image.rs:516-523). */
 enum { RPF_PACK_MSB_FIRST = 0, RPF_PACK_LSB_FIRST = 1, RPF_PACK_MIPI = 2 };
@@ -261,8 +261,8 @@ int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_para
 int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* raw, void* d_out, int out_format,
                     void* stream);
 /* The same with the integer unpack folded into the kernel's row loads: d_packed holds the band's (rows + 4) rows in the
- * packed layout of rpf_dev_unpack_bayer (either bit order, bits in {10, 12, 14, 16}), row r = frame row y0 - 2 + r, rows
- * row_stride bytes apart.  Same output bits as rpf_dev_unpack_bayer followed by rpf_dev_develop, one pass less. */
+ * packed layout of rpf_dev_unpack_bayer (any of its orders and widths; RPF_PACK_MIPI rows need row_stride >= 8),
+ * row r = frame row y0 - 2 + r, rows row_stride bytes apart.  Same output bits as rpf_dev_unpack_bayer followed by rpf_dev_develop, one pass less. */
 int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits, uint32_t order,
                            const rpf_raw_params* raw, void* d_out, int out_format, void* stream);
 /* the reference-equivalent back half: RGBA32F tile in -> out (wgsl main) */

@@ -886,13 +886,19 @@ int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_st
 {
     int rc = need_device(e);
     if (rc) return rc;
-    if (order == RPF_PACK_MIPI)
-        return fail(RPF_ERR_INVALID_ARGUMENT, "MIPI-packed rows go through rpf_dev_unpack_bayer, then rpf_dev_develop");
-    if (order > RPF_PACK_LSB_FIRST) return fail(RPF_ERR_INVALID_ARGUMENT, "unknown bit order");
+    if (order > RPF_PACK_MIPI) return fail(RPF_ERR_INVALID_ARGUMENT, "unknown bit order");
     if (!d_packed || !raw || !d_out) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
-    if (bits != 10 && bits != 12 && bits != 14 && bits != 16)
-        return fail(RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT, "Unsupported read image format: packed samples must be 10, 12, 14 or 16 bits");
-    if (row_stride < ((size_t)e->geom.width * bits + 7) / 8 || row_stride > 0xffffffffu)
+    if (bits != 10 && bits != 12 && bits != 14 && (bits != 16 || order == RPF_PACK_MIPI))
+        return fail(RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT,
+                    order == RPF_PACK_MIPI ? "Unsupported read image format: MIPI-packed samples must be 10, 12 or 14 bits"
+                                           : "Unsupported read image format: packed samples must be 10, 12, 14 or 16 bits");
+    size_t need = ((size_t)e->geom.width * bits + 7) / 8;
+    if (order == RPF_PACK_MIPI) {  // whole CSI-2 groups; the kernel reads a group through an 8-byte window
+        const size_t n = bits == 12 ? 2 : 4;
+        need = ((size_t)e->geom.width + n - 1) / n * (n + n * (bits - 8) / 8);
+        if (need < 8) need = 8;
+    }
+    if (row_stride < need || row_stride > 0xffffffffu)
         return fail(RPF_ERR_INVALID_ARGUMENT, "row_stride shorter than a packed row");
     HIP_TRY(hipSetDevice(e->proc->device));
     if ((rc = sync_edit_state(e))) return rc;

@@ -93,3 +93,20 @@ def pack_msb(cfa: np.ndarray, bits: int) -> np.ndarray:
     rows, w = cfa.shape
     b = np.unpackbits(np.ascontiguousarray(cfa).astype(">u2").view(np.uint8).reshape(rows, w, 2), axis=2)[:, :, 16 - bits:]
     return np.packbits(b.reshape(rows, w * bits), axis=1)
+
+
+def pack_mipi(cfa: np.ndarray, bits: int) -> np.ndarray:
+    """MIPI CSI-2 RAW10 / RAW12 / RAW14 packing of a (rows, width) u16 plane (width a multiple of the group size):
+    groups of 4 / 2 / 4 pixels in 5 / 3 / 7 bytes, high bytes first, then the low bits LSB-first in pixel order
+    (RPF_PACK_MIPI of include/rpf.h); rows padded to a multiple of 8 bytes."""
+    rows, w = cfa.shape
+    n, low = (2 if bits == 12 else 4), bits - 8
+    if w % n:
+        raise ValueError("width must be a multiple of the CSI-2 group size")
+    v = np.ascontiguousarray(cfa).astype(np.uint32).reshape(rows, w // n, n)
+    hi = (v >> low).astype(np.uint8)
+    lowbits = np.unpackbits((v & ((1 << low) - 1)).astype(np.uint8)[..., None], axis=3, bitorder="little")[..., :low]
+    lo = np.packbits(lowbits.reshape(rows, w // n, n * low), axis=2, bitorder="little")
+    out = np.concatenate([hi, lo], axis=2).reshape(rows, -1)
+    pad = (-out.shape[1]) % 8
+    return np.pad(out, ((0, 0), (0, pad))) if pad else out

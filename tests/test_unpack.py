@@ -157,8 +157,7 @@ def test_gpu_unpack_rejects_bad_arguments(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("order", [0, 1])
-@pytest.mark.parametrize("bits", [10, 12, 14, 16])
+@pytest.mark.parametrize("bits,order", [(b, o) for o in (0, 1, 2) for b in (10, 12, 14, 16) if not (o == 2 and b == 16)])
 def test_gpu_fused_unpack_develop_bit_exact(gpu, bits, order):
     """rpf_dev_develop_packed == unpack (oracle, integer) followed by the oracle's develop, on whole frames and on row
     bands with halo rows, ragged widths, padded / odd row strides, all three output layouts."""
@@ -173,7 +172,7 @@ def test_gpu_fused_unpack_develop_bit_exact(gpu, bits, order):
         cfa = rng.integers(0, white + 1, (h, w), dtype=np.uint16)
         p = {"D": util.params_D, "S": util.params_S, "G": util.params_G}[pname]()
         want = O.develop(cfa, rp, [p])
-        stride = O.packed_row_stride(w, bits) + extra
+        stride = max(O.packed_row_stride(w, bits, order=order), 8) + extra   # MIPI rows: >= 8 bytes (the kernel's window)
         # whole frame: halo rows exist in the buffer but are never read (reflect-101 at the frame edge)
         pad = np.zeros((h + 4, w), np.uint16)
         pad[2:-2] = cfa
@@ -209,6 +208,12 @@ def test_gpu_fused_unpack_develop_rejects_bad_arguments(gpu):
         ed.dev_develop_packed(buf.data_ptr(), 96, 11, raw, out.data_ptr())            # unsupported width
     with pytest.raises(R.InvalidArgument):
         ed.dev_develop_packed(buf.data_ptr(), 95, 12, raw, out.data_ptr())            # stride shorter than a row
+    with pytest.raises(R.PhotoEditorError):
+        ed.dev_develop_packed(buf.data_ptr(), 128, 16, raw, out.data_ptr(), order=R.PACK_MIPI)   # no CSI-2 RAW16 here
+    with pytest.raises(R.InvalidArgument):
+        ed.dev_develop_packed(buf.data_ptr(), 79, 10, raw, out.data_ptr(), order=R.PACK_MIPI)    # 16 groups = 80 bytes
+    with pytest.raises(R.InvalidArgument):
+        ed.dev_develop_packed(buf.data_ptr(), 96, 12, raw, out.data_ptr(), order=3)              # unknown order
     ed.set_lens_distortion_correction(20)
     with pytest.raises(R.InvalidArgument):
         ed.dev_develop_packed(buf.data_ptr(), 96, 12, raw, out.data_ptr())            # needs the whole-frame pass
