@@ -283,20 +283,17 @@ struct HueBoundCs {
     float cs_km1[2];
 };
 
-// `bd_out` / `passed_out`: the table entry that was read and the side of its boundary (for hue_index_cs).
-// NEG_ZERO_X = false: the caller's promise that x is never -0 while y is +-0 (then atan2 = +-pi, index 32767, is the
-// one result no boundary decides); it saves the two compares and the merge that exist for that argument alone.
-template <bool NEG_ZERO_X = true, class Entry>
-RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out, bool& passed_out, uint32_t& zero_negx_out)
+// The approximate position of the direction (x, y) on the index scale, in [0, 65535.x]: atan2 / (2 pi), wrapped, times
+// 65535, within 0.125 of the true value (the polynomial — tools/gen_math_consts.py — plus the reciprocal and the binary32
+// evaluation; measured maximum 0.1227 over 8 M directions, tests/test_math_exhaustive.py).
+RPF_HD float hue_candidate(float y, float x, float& mx_out)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
     // q = min / max in [0, 1] feeds the approximation only (its error budget is 0.38 index units, a hardware
     // reciprocal's 1 ulp is nothing).  The larger magnitude is clamped into [2^-100, 2^100] first: the floor keeps
     // a = b = 0 at q = 0 instead of 0 * inf, the ceiling keeps the reciprocal a normal number — outside that range
     // (which the chain cannot reach: |a|, |b| < 8, and a nonzero one is > 2^-75) the candidate may be off and the
-    // function is not specified.  Straight-line code on purpose: written as a select around the table read, the
-    // compiler turns it into a branch per pixel with the gather and its wait inside, which serialises the pair
-    // and exposes the whole L2 latency.
+    // function is not specified.
 #if defined(__HIP_DEVICE_COMPILE__)
     // one v_max_f32 / v_min_f32 each with |.| source modifiers (through fmaxf / fminf the compiler first
     // "canonicalises" both magnitudes with a v_max of their own: four half-rate instructions instead of two)
@@ -320,11 +317,35 @@ RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out,
     v = ay > ax ? 16383.75f - v : v;   // pi/2 - a
     v = x < 0.0f ? 32767.5f - v : v;   // pi - a
     v = y < 0.0f ? 65535.0f - v : v;   // 2 pi - a (the wrap of wgsl:73); y = -0 counts as +0, like atan2's -0 result
+    mx_out = mx;
+    return v;
+}
+
+// `bd_out` / `passed_out`: the table entry that was read and the side of its boundary (for hue_index_cs).
+// NEG_ZERO_X = false: the caller's promise that x is never -0 while y is +-0 (then atan2 = +-pi, index 32767, is the
+// one result no boundary decides); it saves the two compares and the merge that exist for that argument alone.
+template <bool NEG_ZERO_X = true, bool SPARSE = false, class Entry>
+RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out, bool& passed_out, uint32_t& zero_negx_out)
+{
+    float mx;
+    const float v = hue_candidate(y, x, mx);
     // nearest integer of v in [0, 65535.x] without a conversion (half-rate on gfx950): the low bits of v + 2^23
-    const uint32_t j = f2bits(v + 8388608.0f) & 0xffffu;
-    const Entry bd = hb[j];
+    const float vr = v + 8388608.0f;
+    const uint32_t j = f2bits(vr) & 0xffffu;
+    // SPARSE: v is within 0.125 index units of the true position and boundary j lies within 0.007 of position j (the
+    // reference pipeline's own roundings shape it; both measured in tests/test_math_exhaustive.py), so a candidate at
+    // least 3/16 away from the integer it rounds to has its side of boundary j settled by v alone.  Only
+    // the other lanes (37.5 % for uniformly distributed hues) look their boundary up; the rest read entry 0, one cache
+    // line for all of them.  A wavefront's gather touches one 128-byte line per distinct entry, and at two gathers per
+    // step that traffic, not its latency, is what the table costs (profiles/r02_experiments.md).
+    // Straight-line code on purpose (the ENTRY is selected, not the read): written as a select around the table read, the
+    // compiler turns it into a branch per pixel with the gather and its wait inside, which serialises the pair and
+    // exposes the whole L2 latency.
+    const float frac = v - (vr - 8388608.0f);  // exact: v - round(v), in [-0.5, 0.5]
+    const bool near = !SPARSE || __builtin_fabsf(frac) < 0.1875f;
+    const Entry bd = hb[near ? j : 0u];
     const double d = __builtin_fma((double)y, bd.c, -((double)x * bd.s));
-    const bool passed = d >= 0.0;
+    const bool passed = near ? d >= 0.0 : frac >= 0.0f;
     const uint32_t k = (j - (passed ? 0u : 1u)) & 0xffffu;
     bd_out = bd;
     passed_out = passed;
@@ -341,7 +362,7 @@ RPF_HD uint32_t hue_index(float y, float x, const HueBound* hb)
     HueBound bd;
     bool passed;
     uint32_t zn;
-    return hue_index_core<NEG_ZERO_X>(y, x, hb, bd, passed, zn);
+    return hue_index_core<NEG_ZERO_X, true>(y, x, hb, bd, passed, zn);
 }
 
 // The index together with cos / sin of ITS hue angle (= sincos_hue(k)), read from the same table entry: for

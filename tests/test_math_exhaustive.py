@@ -196,6 +196,43 @@ def test_hue_index_next_to_every_boundary():
             assert np.array_equal(a, b), (radius, steps, np.nonzero(a != b)[0][:10])
 
 
+def test_hue_candidate_error_and_the_sparse_lookup_threshold():
+    """hue_index looks a boundary up only when the candidate position is within 3/16 of an integer; everywhere else the
+    candidate alone decides.  That needs |candidate - true position| < 3/16: measured here against binary64 (the
+    device's v_rcp_f32 instead of the host's division moves it by ~1e-3), and the index itself is checked at true
+    positions all around the threshold, on both sides of every boundary."""
+    tw = util.twin()
+    rng = np.random.default_rng(23)
+    n = 8_000_000
+    th = rng.uniform(-np.pi, np.pi, n)
+    r = 10.0 ** rng.uniform(-8, 0.5, n)
+    y, x = (r * np.sin(th)).astype(np.float32), (r * np.cos(th)).astype(np.float32)
+    v = np.empty(n, np.float32)
+    tw.twin_hue_candidate_many(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                               v.ctypes.data_as(C.c_void_p))
+    t = np.arctan2(y.astype(np.float64), x.astype(np.float64)) / (2 * np.pi)
+    u = np.where(t < 0, t + 1.0, t) * 65535.0
+    err = np.abs(v.astype(np.float64) - u)
+    err = np.minimum(err, 65535.0 - err)       # the wrap at angle 0
+    assert err.max() < 0.125, err.max()
+    # ... and boundary j sits at position j up to the reference pipeline's own roundings
+    c, s = C.c_double(), C.c_double()
+    pos = np.empty(65536)
+    for k in range(65536):
+        tw.twin_hue_bound(C.c_uint32(k), C.byref(c), C.byref(s))
+        pos[k] = np.arctan2(s.value, c.value)
+    pos = np.where(pos < 0, pos + 2 * np.pi, pos) * (65535.0 / (2 * np.pi))
+    assert np.abs(pos - np.arange(65536)).max() < 0.01        # 0.125 + 0.01 + the device reciprocal's 1e-3 < 3/16
+    # true positions j + off for every boundary j, off around +-3/16 and across the whole cell
+    j = np.arange(65536, dtype=np.float64)
+    for radius in (0.8, 1e-3):
+        for off in (-0.49, -0.3, -0.2, -0.19, -0.1875, -0.18, -0.17, -0.05, 0.05, 0.17, 0.18, 0.1875, 0.19, 0.2, 0.3, 0.49):
+            ang = (j + off) * (2 * np.pi / 65535.0)
+            rr = radius * rng.uniform(0.5, 1.0, ang.size)
+            a, b = _hue_both(rr * np.sin(ang), rr * np.cos(ang))
+            assert np.array_equal(a, b), (radius, off, np.nonzero(a != b)[0][:10])
+
+
 def test_hue_index_special_arguments():
     z, nz = 0.0, -0.0
     cases = [(z, z), (nz, z), (z, nz), (nz, nz), (z, 1), (nz, 1), (z, -1), (nz, -1), (1, z), (1, nz), (-1, z), (-1, nz),

@@ -89,6 +89,14 @@ void twin_hue_index_many(const float* y, const float* x, size_t n, uint32_t* out
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < (long long)n; ++i) out[i] = rpf::hue_index(y[i], x[i], hb);
 }
+void twin_hue_candidate_many(const float* y, const float* x, size_t n, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) {
+        float mx;
+        out[i] = rpf::hue_candidate(y[i], x[i], mx);
+    }
+}
 void twin_hue_bound(uint32_t j, double* c, double* s) { *c = hue_bounds_tab()[j].c; *s = hue_bounds_tab()[j].s; }
 float twin_srgb_to_linear(float c) { return rpf::srgb_to_linear1(c, legacy_tabs().decode); }
 float twin_vignette_gain(int legacy, float strength, int x, int y, float w, float h)
