@@ -11,11 +11,13 @@ run --workload demosaic
 for p in D S G V T; do run --workload develop --params $p; done
 run --workload develop --data N
 run --workload develop_packed
+run --workload develop_packed --pack mipi
 run --workload unpack
 run --workload apply --params D
 run --workload apply --params S
+run --workload apply --params G
 run --workload develop --out rgb
 run --workload develop --out u8
-for m in 2 4 8; do run --workload develop --masks $m; done
+for m in 2 4 8 16; do run --workload develop --masks $m; done
 run --workload batch --frames 16
 run --workload batch --frames 16 --no-prefetch
