@@ -248,6 +248,29 @@ def test_row_tiles_with_halo_equal_whole_frame(gpu):
         assert_parity(lin.cpu().numpy(), O.demosaic(cfa, rp, y0=y0, rows=rows))
 
 
+def test_bands_of_a_very_tall_frame(gpu):
+    """The geometry of the 8-GPU weak-scaling run (bench.py --gpus 8: frame 6000 x 32000, band y0 = rank * 4000): a band
+    far down a frame that is much taller than wide — row reflection at the frame's last rows, the vignette's global
+    coordinates (wgsl:169 uses the FRAME's size) and 32-bit row offsets with a large y0 — against the oracle."""
+    torch = pytest.importorskip("torch")
+    h, w = 32000, 96
+    cfa = util.bayer_uniform(h, w)
+    rp = util.raw_params()
+    p = util.params_S()   # vignette, every tone slider, a brightness curve
+    want = O.develop(cfa, rp, [p])
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:-2] = cfa
+    s = torch.cuda.current_stream().cuda_stream
+    for y0, rows in ((28000, 4000), (0, 4000), (15998, 4), (31990, 10)):
+        band = torch.from_numpy(pad[y0:y0 + rows + 4].copy().view(np.int16)).cuda()
+        out = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
+        ed = R.PhotoEditor.for_tile(gpu, w, h, y0, rows)
+        util.configure_editor(ed, p)
+        ed.dev_develop(band.data_ptr(), util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32, s)
+        torch.cuda.synchronize()
+        assert_parity(out.cpu().numpy(), want[y0:y0 + rows])
+
+
 def test_output_formats_of_the_fused_kernel(gpu):
     torch = pytest.importorskip("torch")
     h, w = 64, 200
