@@ -670,6 +670,17 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     };
     uint32_t base = blockIdx.x * NT * 2;
     if (!LENS && base < npix) fetch(base);
+    // The pixels' coordinates (vignette): one division per thread at the start, then carried from step to step — a step
+    // moves every pixel by the same (stride / W, stride % W).  (Per pixel and step the 32-bit division alone was ~25
+    // instructions.)  Pixels past the end of the image get coordinates too; nothing of theirs is stored.
+    const uint32_t step_y = stride / (uint32_t)W, step_x = stride - step_y * (uint32_t)W;
+    uint32_t cx[2], cy[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t p = base + (uint32_t)k * NT + tid;
+        cy[k] = p / (uint32_t)W;
+        cx[k] = p - cy[k] * (uint32_t)W;
+    }
     for (; base < npix; base += stride) {
         float r[2], g[2], b[2];
         uint32_t active[2] = {1u, 1u};
@@ -691,7 +702,9 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         if (coords) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int ry = (int)(pix[k] / (uint32_t)W), x = (int)(pix[k] - (uint32_t)ry * (uint32_t)W);
+                // LENS (whole frame, every source coordinate must exist): from the clamped pixel index
+                const int ry = LENS ? (int)(pix[k] / (uint32_t)W) : (int)cy[k];
+                const int x = LENS ? (int)(pix[k] - (uint32_t)ry * (uint32_t)W) : (int)cx[k];
                 const int gy = (int)a.g.y0 + ry;
                 if (LENS)  // wgsl:123-163; a.in is the whole frame
                     lens_sample(TexFetch{a.in, W}, W, H, x, gy, a.ed.lens_strength, r[k], g[k], b[k]);
@@ -721,6 +734,15 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
             reinterpret_cast<unsigned char*>(a.out) + (size_t)base * BPP, 0, (int)(span(base) * BPP), RPF_BUFFER_RSRC_FLAGS);
 #pragma unroll
         for (int k = 0; k < 2; ++k) store_px_buf<OUTFMT>(ors, ((uint32_t)k * NT + tid) * BPP, r[k], g[k], b[k]);
+        if (coords && !LENS) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                cx[k] += step_x; cy[k] += step_y;
+                const bool wrap = cx[k] >= (uint32_t)W;
+                cx[k] -= wrap ? (uint32_t)W : 0u;
+                cy[k] += wrap ? 1u : 0u;
+            }
+        }
     }
 }
 
