@@ -405,10 +405,27 @@ RPF_HD float sqrt_cr(float s)
 // pow(x, 1.5) correctly rounded for x in [0, 1] (vignette falloff, wgsl:171): x * sqrt(x) in binary64 is within
 // 2^-52 of the true value, and exact whenever the result is exactly representable or a binary32 tie (x a perfect
 // square).  (The table scheme of powc was tried for it: same kernel time, and it needs a tie fix-up.)
+// On the device the binary64 square root (the compiler's expansion: ~17 binary64-rate instructions) is replaced by what
+// the binary32 one leaves over: s = sqrt_cr(x) is correctly rounded, so with r = x - s^2 (exact in one fma)
+//   x^1.5 = x s + r s / 2 + (3/8) r^2 / s + O(r^3),   x s exact in binary64, 1 / s from v_rsq_f32 (any value within
+// 2 ulp of it gives the same bits), the remainder below 2^-70 relative.  Five binary64 operations.  For x in
+// {0} u [2^-96, 1] — the vignette's argument is 0 or at least 3.9e-8 — the result has the bits of the formulation above
+// for EVERY binary32 of that set: checked on the GPU (tests/test_gpu_math.py).  The host build is the formulation above.
 RPF_HD float pow_1p5(float x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float g = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * g;
+    const float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * g, s0);  // sqrt_cr's Markstein step
+    const double sd = (double)s, xd = (double)x;
+    const double r = __builtin_fma(-sd, sd, xd);
+    const double q = (double)(0.375f * g) * r;
+    const double res = __builtin_fma(q, r, __builtin_fma(r, (double)(0.5f * s), xd * sd));
+    return x > 0.0f ? (float)res : 0.0f;  // x = 0: g = inf and everything above is NaN
+#else
     const double xd = (double)x;
     return (float)(xd * __builtin_sqrt(xd));
+#endif
 }
 
 // pow(x, 4.0) correctly rounded for finite x >= 0 (Godot-legacy vignette falloff): x^2 is exact in binary64,

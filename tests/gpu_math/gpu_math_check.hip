@@ -27,6 +27,49 @@ __global__ void k_check_sqrt(uint32_t lo, uint64_t n, unsigned long long* bad, u
     if (mine) atomicAdd(bad, mine);
 }
 
+// pow_1p5(x) against the binary64 formulation (float)(x * sqrt(x)) with the compiler's IEEE square root
+__global__ void k_check_pow_1p5(uint32_t lo, uint64_t n, unsigned long long* bad, uint32_t* first_bad)
+{
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = rpf::bits2f(lo + (uint32_t)i);
+        const float got = rpf::pow_1p5(x);
+        volatile double xv = (double)x;
+        const float ref = (float)(xv * __builtin_sqrt(xv));
+        if (rpf::f2bits(got) != rpf::f2bits(ref)) {
+            ++mine;
+            atomicMin(first_bad, lo + (uint32_t)i);
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+template <class K>
+static int run_check(K kernel, uint32_t lo_bits, uint64_t n, uint64_t* mismatches, uint32_t* first_bad_bits)
+{
+    unsigned long long* d_bad = nullptr;
+    uint32_t* d_first = nullptr;
+    if (hipMalloc((void**)&d_bad, sizeof(*d_bad)) != hipSuccess) return 1;
+    if (hipMalloc((void**)&d_first, sizeof(*d_first)) != hipSuccess) return 1;
+    const uint32_t ff = 0xffffffffu;
+    (void)hipMemset(d_bad, 0, sizeof(*d_bad));
+    (void)hipMemcpy(d_first, &ff, sizeof(ff), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(kernel, dim3(256 * 8), dim3(256), 0, 0, lo_bits, n, d_bad, d_first);
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    unsigned long long bad = 0;
+    (void)hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(first_bad_bits, d_first, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    (void)hipFree(d_first);
+    *mismatches = bad;
+    return 0;
+}
+
+extern "C" int gpu_check_pow_1p5(uint32_t lo_bits, uint64_t n, uint64_t* mismatches, uint32_t* first_bad_bits)
+{
+    return run_check(k_check_pow_1p5, lo_bits, n, mismatches, first_bad_bits);
+}
+
 extern "C" int gpu_check_sqrt(uint32_t lo_bits, uint64_t n, uint64_t* mismatches, uint32_t* first_bad_bits)
 {
     unsigned long long* d_bad = nullptr;

@@ -27,6 +27,8 @@ def checker():
     lib = C.CDLL(build_checker())
     lib.gpu_check_sqrt.restype = C.c_int
     lib.gpu_check_sqrt.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.gpu_check_pow_1p5.restype = C.c_int
+    lib.gpu_check_pow_1p5.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     return lib
 
 
@@ -40,3 +42,14 @@ def test_sqrt_cr_equals_ieee_sqrt_on_every_binary32(checker):
         assert bad.value == 0, f"{bad.value} mismatches in [{lo:#x}, +2^30), first at bits {first.value:#010x}"
         total += 1 << 30
     assert total == 1 << 32
+
+
+def test_pow_1p5_equals_the_binary64_formulation_on_its_whole_domain(checker):
+    """pow_1p5 on the device (sqrt_cr's Markstein step + two correction terms, five binary64 operations) against
+    (float)(x * sqrt(x)) in binary64 — the host build, which tests/test_math_exhaustive.py pins to the oracle — for
+    x = 0 and every binary32 in [2^-96, 1]: the vignette's falloff argument is 0 or >= 3.9e-8 (wgsl:170-171)."""
+    bad, first = C.c_uint64(0), C.c_uint32(0)
+    assert checker.gpu_check_pow_1p5(0, 1, C.byref(bad), C.byref(first)) == 0 and bad.value == 0      # x = +0
+    lo, hi = 0x0f800000, 0x3f800000                                                                    # 2^-96 .. 1.0
+    assert checker.gpu_check_pow_1p5(lo, hi - lo + 1, C.byref(bad), C.byref(first)) == 0
+    assert bad.value == 0, f"{bad.value} mismatches, first at bits {first.value:#010x}"
