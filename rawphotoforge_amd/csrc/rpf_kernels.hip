@@ -798,15 +798,24 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_rgb_int(const T* in, size_t npix, const float* lut, float4* out)
 {
     constexpr float MAXV = sizeof(T) == 1 ? 255.0f : 65535.0f;
+    __shared__ float lds_lut[256];  // the 8-bit table: three look-ups per pixel, served from LDS (16-bit: 256 KiB, from L2)
+    if (sizeof(T) == 1 && lut) {
+        lds_lut[threadIdx.x] = lut[threadIdx.x];
+        __syncthreads();
+    }
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    // the output as one buffer (npix * 16 bytes, below 4 GiB: launch_rgb_int checks); stores nontemporal like the other writers
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(uint32_t)(npix * 16u), RPF_BUFFER_RSRC_FLAGS);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         const uint32_t r = in[i * 3], g = in[i * 3 + 1], b = in[i * 3 + 2];
-        float4 o;
+        float x, y, z;
         if (lut) {  // kernel-uniform
-            o = make_float4(lut[r], lut[g], lut[b], 1.0f);
+            if (sizeof(T) == 1) { x = lds_lut[r]; y = lds_lut[g]; z = lds_lut[b]; }
+            else { x = lut[r]; y = lut[g]; z = lut[b]; }
         } else {
-            o = make_float4((float)r / MAXV, (float)g / MAXV, (float)b / MAXV, 1.0f);  // correctly rounded (hipcc default)
+            x = (float)r / MAXV; y = (float)g / MAXV; z = (float)b / MAXV;  // correctly rounded (hipcc default)
         }
-        out[i] = o;
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{f2bits(x), f2bits(y), f2bits(z), 0x3f800000u}, ors, (uint32_t)i * 16u, 0, 2);
     }
 }
 
@@ -1418,6 +1427,7 @@ hipError_t launch_rgb_int(const void* d_in, int bits, size_t npix, const float* 
     if (npix == 0) return hipSuccess;
     if (!d_in || !d_rgba || (bits != 8 && bits != 16)) return hipErrorInvalidValue;
     if (bits == 16 && (reinterpret_cast<uintptr_t>(d_in) & 1)) return hipErrorInvalidValue;
+    if (npix >= (1ull << 28)) return hipErrorInvalidValue;  // the output is addressed through 32-bit buffer offsets
     const uint32_t grid = (uint32_t)((npix + 255) / 256 > 16384 ? 16384 : (npix + 255) / 256);
     if (bits == 8)
         hipLaunchKernelGGL((k_rgb_int<uint8_t>), dim3(grid), dim3(256), 0, s, static_cast<const uint8_t*>(d_in), npix, d_lut,
