@@ -768,10 +768,17 @@ __global__ __launch_bounds__(256) void k_combine_masks(const uint8_t* planes, ui
     }
 }
 
+// one RGBA32F pixel, nontemporal: these frames are written once and read by a later launch
+__device__ __forceinline__ void store_nt(float4* p, float x, float y, float z, float w)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f{x, y, z, w}, reinterpret_cast<v4f*>(p));
+}
+
 __global__ __launch_bounds__(256) void k_pad_rgb(const float* in, size_t npix, float4* out)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256)
-        out[i] = make_float4(in[i * 3], in[i * 3 + 1], in[i * 3 + 2], 1.0f);
+        store_nt(&out[i], in[i * 3], in[i * 3 + 1], in[i * 3 + 2], 1.0f);
 }
 
 // 16-bit PPM payload -> RGBA32F (web-ts/core/image.ts:172-189): big-endian samples, v / 65535 (binary64 in the
@@ -783,8 +790,7 @@ __global__ __launch_bounds__(256) void k_rgb16be(const uint16_t* in, size_t npix
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         const uint32_t r = __builtin_bswap16(in[i * 3]), g = __builtin_bswap16(in[i * 3 + 1]),
                        b = __builtin_bswap16(in[i * 3 + 2]);
-        out[i] = make_float4(div_u16_by(r, 65535.0f, inv), div_u16_by(g, 65535.0f, inv), div_u16_by(b, 65535.0f, inv),
-                             1.0f);
+        store_nt(&out[i], div_u16_by(r, 65535.0f, inv), div_u16_by(g, 65535.0f, inv), div_u16_by(b, 65535.0f, inv), 1.0f);
     }
 }
 
