@@ -89,3 +89,32 @@ extern "C" int gpu_check_sqrt(uint32_t lo_bits, uint64_t n, uint64_t* mismatches
     *mismatches = bad;
     return 0;
 }
+
+// hue_index on the device (v_rcp_f32 in the candidate, the sparse table lookup) for n directions; bounds = the 65536
+// boundary directions (c, s) the host built (tests pass the twin's table).  neg_zero_x = 0 is the chain's call.
+template <bool NEG_ZERO_X>
+__global__ void k_hue_index(const float* y, const float* x, uint64_t n, const rpf::HueBound* hb, uint32_t* out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = rpf::hue_index<NEG_ZERO_X>(y[i], x[i], hb);
+}
+
+extern "C" int gpu_hue_index(const float* y, const float* x, uint64_t n, const double* bounds, int neg_zero_x, uint32_t* out)
+{
+    float *dy = nullptr, *dx = nullptr;
+    rpf::HueBound* dhb = nullptr;
+    uint32_t* dout = nullptr;
+    static_assert(sizeof(rpf::HueBound) == 16, "HueBound is two doubles");
+    if (hipMalloc((void**)&dy, n * 4) != hipSuccess || hipMalloc((void**)&dx, n * 4) != hipSuccess ||
+        hipMalloc((void**)&dout, n * 4) != hipSuccess || hipMalloc((void**)&dhb, 65536 * 16) != hipSuccess)
+        return 1;
+    (void)hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dhb, bounds, 65536 * 16, hipMemcpyHostToDevice);
+    if (neg_zero_x) hipLaunchKernelGGL(k_hue_index<true>, dim3(2048), dim3(256), 0, 0, dy, dx, n, dhb, dout);
+    else hipLaunchKernelGGL(k_hue_index<false>, dim3(2048), dim3(256), 0, 0, dy, dx, n, dhb, dout);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    (void)hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout); (void)hipFree(dhb);
+    return rc;
+}

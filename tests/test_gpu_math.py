@@ -27,6 +27,8 @@ def checker():
     lib = C.CDLL(build_checker())
     lib.gpu_check_sqrt.restype = C.c_int
     lib.gpu_check_sqrt.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.gpu_hue_index.restype = C.c_int
+    lib.gpu_hue_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpu_check_pow_1p5.restype = C.c_int
     lib.gpu_check_pow_1p5.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     return lib
@@ -53,3 +55,42 @@ def test_pow_1p5_equals_the_binary64_formulation_on_its_whole_domain(checker):
     lo, hi = 0x0f800000, 0x3f800000                                                                    # 2^-96 .. 1.0
     assert checker.gpu_check_pow_1p5(lo, hi - lo + 1, C.byref(bad), C.byref(first)) == 0
     assert bad.value == 0, f"{bad.value} mismatches, first at bits {first.value:#010x}"
+
+
+def test_hue_index_on_the_device_matches_the_oracle(checker):
+    """The device build of hue_index differs from the host twin in one place, the hardware reciprocal inside the
+    candidate, and the candidate now also decides on its own when it is 3/16 or more from an integer: random directions
+    over the chain's magnitudes, and true positions on both sides of that threshold around every boundary, through the
+    device code against the oracle's correctly rounded atan2 pipeline."""
+    import numpy as np
+    import oracle as O
+    from tests import util
+    tw, orc = util.twin(), O.lib()
+    c, s = C.c_double(), C.c_double()
+    bounds = np.empty((65536, 2))
+    for k in range(65536):
+        tw.twin_hue_bound(C.c_uint32(k), C.byref(c), C.byref(s))
+        bounds[k] = (c.value, s.value)
+
+    def both(y, x, neg_zero_x=0):
+        y, x = np.ascontiguousarray(y, np.float32), np.ascontiguousarray(x, np.float32)
+        a, b = np.empty(y.size, np.uint32), np.empty(y.size, np.uint32)
+        assert checker.gpu_hue_index(y.ctypes.data, x.ctypes.data, y.size, bounds.ctypes.data, neg_zero_x, a.ctypes.data) == 0
+        orc.orc_hue_index_many(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_size_t(y.size),
+                               b.ctypes.data_as(C.c_void_p))
+        return a, b
+
+    rng = np.random.default_rng(31)
+    n = 16_000_000
+    th = rng.uniform(-np.pi, np.pi, n)
+    r = 10.0 ** rng.uniform(-8, 0.5, n)
+    for nz in (0, 1):
+        a, b = both(r * np.sin(th), r * np.cos(th), nz)
+        assert np.array_equal(a, b), np.nonzero(a != b)[0][:10]
+    j = np.arange(65536, dtype=np.float64)
+    for radius in (0.8, 1e-3):
+        for off in (-0.49, -0.2, -0.19, -0.1875, -0.18, -0.05, -1e-4, 1e-4, 0.05, 0.18, 0.1875, 0.19, 0.2, 0.49):
+            ang = (j + off) * (2 * np.pi / 65535.0)
+            rr = radius * rng.uniform(0.5, 1.0, ang.size)
+            a, b = both(rr * np.sin(ang), rr * np.cos(ang))
+            assert np.array_equal(a, b), (radius, off, np.nonzero(a != b)[0][:10])
