@@ -30,6 +30,15 @@ except O.PchipError:
 for bits in (10, 12, 14, 16):
     a = rng.integers(0, 1 << bits, (3, 37), dtype=np.uint16)
     assert np.array_equal(O.unpack_bayer(O.pack_bayer(a, bits), 37, bits), a)
+    for order in (O.PACK_LSB_FIRST, O.PACK_MIPI):   # ragged rows: the last CSI-2 group / the last byte are partial
+        if order == O.PACK_MIPI and bits == 16:
+            continue
+        for w in (1, 3, 37):
+            assert np.array_equal(O.unpack_bayer(O.pack_bayer(a[:, :w], bits, order=order), w, bits, order=order), a[:, :w])
+for dt in (np.uint8, np.uint16):    # decoded-image ingest, with and without a table
+    img = rng.integers(0, np.iinfo(dt).max + 1, (5, 7, 3), dtype=dt)
+    O.rgb_int_to_rgba(img)
+    O.rgb_int_to_rgba(img, rng.random(np.iinfo(dt).max + 1, dtype=np.float32))
 O.resize_long_edge(rng.random((33, 5, 3), dtype=np.float32), 7)
 O.legacy_tone_lut(0.5, 20, 30, -20, 5, -5)
 O.legacy_apply_gamma(rng.random(1000, dtype=np.float32), (2.222, 4.5))
