@@ -64,10 +64,14 @@ __device__ __forceinline__ const MaskParams& mask_params_main(const LdsMaskParam
 __device__ __forceinline__ MaskParams mask_params_user(const LdsMaskParams& s, uint32_t m)
 {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(3))) v4u* lds_v4u_ptr;
     static_assert(sizeof(MaskParams) == 48, "three 16-byte reads");
     const uint32_t a = s.lds_base + m * 48u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(3))) v4u* lds_v4u_ptr;
     const v4u q0 = *(lds_v4u_ptr)(a), q1 = *(lds_v4u_ptr)(a + 16u), q2 = *(lds_v4u_ptr)(a + 32u);
+#else  // host pass of the HIP compilation (never called; an LDS address is not a host pointer)
+    const v4u q0 = {a, 0, 0, 0}, q1 = q0, q2 = q0;
+#endif
     MaskParams P;
     P.r_gain = bits2f(q0.x); P.g_gain = bits2f(q0.y); P.b_gain = bits2f(q0.z); P.exposure_mul = bits2f(q0.w);
     P.shadow = bits2f(q1.x); P.highlight = bits2f(q1.y); P.black = bits2f(q1.z); P.white = bits2f(q1.w);
