@@ -651,7 +651,8 @@ def test_incremental_setter_traffic(gpu):
     check()
 
 
-@pytest.mark.parametrize("extra", [[], ["--workload", "batch", "--frames", "3"]])
+@pytest.mark.parametrize("extra", [[], ["--workload", "batch", "--frames", "3"],
+                                   ["--workload", "develop_packed", "--pack", "mipi"]])
 def test_bench_prints_one_contract_line(gpu, capsys, monkeypatch, extra):
     """bench.py's output contract: ONE JSON line with the fields the driver and the judge read (the headline workload,
     and BASELINE configs[4]'s batch of different frames)."""

@@ -68,6 +68,21 @@ def test_oracle_known_answers_mipi():
             assert np.array_equal((hi << (bits - 8)) | lo, a)
 
 
+def test_the_benchmarks_packers_write_the_layouts_the_oracle_reads():
+    """bench.py packs its synthetic frame with rawphotoforge_amd/synthetic.py (numpy; the product must not import the
+    oracle): MSB-first bit stream and MIPI CSI-2 groups, both equal to the oracle's packers byte for byte."""
+    from rawphotoforge_amd import synthetic as syn
+    rng = np.random.default_rng(11)
+    for bits in (10, 12, 14):
+        a = rng.integers(0, 1 << bits, (6, 64), dtype=np.uint16)
+        p = syn.pack_mipi(a, bits)
+        assert p.shape[1] % 8 == 0 and np.array_equal(p, O.pack_bayer(a, bits, p.shape[1], order=O.PACK_MIPI))
+        q = syn.pack_msb(a, bits)
+        assert np.array_equal(q, O.pack_bayer(a, bits, q.shape[1]))
+    with pytest.raises(ValueError):
+        syn.pack_mipi(np.zeros((2, 6), np.uint16), 10)      # 6 pixels are not whole RAW10 groups
+
+
 @pytest.mark.parametrize("bits", [10, 12, 14, 16])
 def test_oracle_round_trip(bits):
     rng = np.random.default_rng(bits)
