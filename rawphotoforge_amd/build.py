@@ -15,7 +15,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpf_hip.so")
-SOURCES = ["rpf_kernels.hip", "rpf_api.cpp", "rpf_tables.cpp"]
+# (source, object, extra flags).  rpf_kernels.hip is built as two translation units (see RPF_TU in the file): the
+# rolling-window kernels under the scheduler's max-ILP strategy, the rest under the default one.
+UNITS = [("rpf_kernels.hip", "rpf_kernels_stream.o", ["-DRPF_TU=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+         ("rpf_kernels.hip", "rpf_kernels_rest.o", ["-DRPF_TU=2"]),
+         ("rpf_api.cpp", "rpf_api.o", []),
+         ("rpf_tables.cpp", "rpf_tables.o", [])]
+SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["rpf_math.h", "rpf_chain.h", "rpf_host.h", "rpf_launch.h", os.path.join("..", "..", "include", "rpf.h")]
 ARCH = "gfx950"
 
@@ -32,10 +38,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    for src, objname, extra in UNITS:
+        obj = os.path.join(CSRC, objname)
         cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
-               "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Wall", "-Wno-unused-function"] + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

@@ -315,6 +315,15 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
 // ---------------------------------------------------------------------------
 // k_stream — rolling-window front end
 // ---------------------------------------------------------------------------
+// This file builds as one translation unit (RPF_TU undefined or 0: tests, tools, a plain `hipcc -c`) or as two
+// (build.py): RPF_TU == 1, the rolling-window kernels and their launchers, compiled with the scheduler's max-ILP strategy
+// (fused develop -1.9 %, the RGBA pass with all four curves +3.8 %: profiles/r02_experiments.md), and RPF_TU == 2,
+// everything else with the default strategy.
+#ifndef RPF_TU
+#define RPF_TU 0
+#endif
+
+#if RPF_TU != 2
 constexpr int STRIP_W = 64;  // one wavefront = 64 output columns: every store instruction is one aligned KiB
 
 struct StreamArgs {
@@ -616,6 +625,9 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
     }
 }
 
+#endif  // RPF_TU != 2
+
+#if RPF_TU != 1
 // ---------------------------------------------------------------------------
 // k_apply — wgsl main on an RGBA32F tile (the reference's own pass), 2 pixels per thread
 // ---------------------------------------------------------------------------
@@ -997,6 +1009,8 @@ __global__ __launch_bounds__(256) void k_unpack_mipi(const uint8_t* packed, size
     }
 }
 
+#endif  // RPF_TU != 1
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1037,6 +1051,7 @@ static hipError_t check_edit(const DeviceEdit& ed)
     return hipSuccess;
 }
 
+#if RPF_TU != 2
 struct PackedRows {  // bit-packed input of the fused kernel (bits == 0: d_cfa is a u16 plane)
     uint32_t bits, row_stride, lsb;
 };
@@ -1270,6 +1285,9 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
     }
 }
 
+#endif  // RPF_TU != 2
+
+#if RPF_TU != 1
 template <bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE>
 static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
 {
@@ -1457,5 +1475,7 @@ hipError_t launch_rgb16be(const uint8_t* d_in, size_t npix, float* d_rgba, hipSt
                        reinterpret_cast<float4*>(d_rgba));
     return hipGetLastError();
 }
+
+#endif  // RPF_TU != 1
 
 }  // namespace rpf
