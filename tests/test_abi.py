@@ -62,3 +62,27 @@ def test_version_and_last_error():
     assert N.lib().rpf_editor_create_headless(2, 2, None) == N.ERR_INVALID_ARGUMENT
     assert "null" in N.last_error()
     del h
+
+
+def _build_c_host(tmp_path):
+    """tests/c_host/host_check.c as strict C99 against include/rpf.h, linked with the in-tree library."""
+    from rawphotoforge_amd import build as b
+    exe = str(tmp_path / "host_check")
+    libdir = os.path.dirname(b.LIB)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(util.ROOT, "include"),
+                    os.path.join(util.ROOT, "tests", "c_host", "host_check.c"), "-o", exe, "-L", libdir, "-lrpf_hip",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_drives_the_device_free_part(tmp_path):
+    """The boundary as a cgo / JNI / Rust binding sees it: the header compiles as pedantic C99 and a C program exercises
+    operator state, PCHIP, the PPM header grammar and the error reporting — none of which needs a GPU."""
+    out = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "host_check ok" in out.stdout, out.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_develops_a_frame(tmp_path):
+    out = subprocess.run([_build_c_host(tmp_path), "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "host_check ok" in out.stdout, out.stderr
