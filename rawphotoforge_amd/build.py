@@ -4,7 +4,9 @@ hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the parity con
 oracle rounds after every binary32 operation (oracle/rpf_oracle.c), so must the kernels and
 the host-side f32 arithmetic (PCHIP, parameter conversion).  -fno-slp-vectorize: on gfx950 a v_pk_*_f32
 costs two plain f32 instructions' issue time (tools/microbench.hip), so SLP packing only adds the v_mov
-traffic that builds the register pairs.
+traffic that builds the register pairs.  The rolling-window kernels (the fused chain) are their own translation unit,
+compiled with -mllvm -amdgpu-sched-strategy=max-ilp: same instructions, 93 instead of 78 VGPRs, fewer waits, -2 %
+(profiles/r02_experiments.md); instruction scheduling does not touch the arithmetic, and the parity tests run on this build.
 """
 from __future__ import annotations
 
