@@ -261,7 +261,8 @@ int rpf_dev_demosaic(rpf_processor* p, const uint16_t* d_cfa, const rpf_raw_para
 int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* raw, void* d_out, int out_format,
                     void* stream);
 /* The same with the integer unpack folded into the kernel's row loads: d_packed holds the band's (rows + 4) rows in the
- * packed layout of rpf_dev_unpack_bayer (any of its orders and widths; RPF_PACK_MIPI rows need row_stride >= 8),
+ * packed layout of rpf_dev_unpack_bayer (any of its orders and widths; RPF_PACK_MIPI rows need row_stride >= 8 and, like every row,
+ * row_stride readable bytes: the kernel reads a CSI-2 group through an 8-byte window),
  * row r = frame row y0 - 2 + r, rows row_stride bytes apart.  Same output bits as rpf_dev_unpack_bayer followed by rpf_dev_develop, one pass less. */
 int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_stride, uint32_t bits, uint32_t order,
                            const rpf_raw_params* raw, void* d_out, int out_format, void* stream);
