@@ -1,0 +1,67 @@
+// store_probe.hip — does the order in which a frame's 1-KiB row pieces are written matter?  (measurement tool)
+//   hipcc --offload-arch=gfx950 -O3 tools/store_probe.hip -o tools/store_probe && tools/store_probe
+// 384 MB (6000x4000 RGBA32F: 4000 rows of 96 000 B) written with nontemporal 16-byte stores, 1 KiB per wave-instruction:
+//   linear   wave-instruction k of the launch writes KiB k (a fill)
+//   strips   a wave owns a 64-pixel strip (1 KiB per row) and walks down 32 rows (the fused kernel's item), items dealt
+//            round-robin to the resident waves
+//   strips2  the same, but a wave owns TWO neighbouring strips and writes both rows pieces back to back (2 KiB contiguous)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+constexpr int W = 6000, H = 4000;
+constexpr size_t ROWB = (size_t)W * 16;
+
+__global__ __launch_bounds__(256) void k_linear(unsigned char* out, size_t nkib)
+{
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+    const uint32_t lane = threadIdx.x & 63;
+    for (size_t k = wave; k < nkib; k += nw)
+        __builtin_nontemporal_store(v4u{1, 2, 3, 4}, reinterpret_cast<v4u*>(out + k * 1024 + lane * 16));
+}
+
+template <int NSTRIP>
+__global__ __launch_bounds__(256) void k_strips(unsigned char* out)
+{
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, lane = threadIdx.x & 63;
+    const uint32_t strips = (W + 63) / 64 / NSTRIP, segs = H / 32;
+    for (uint32_t item = wave; item < strips * segs; item += nw) {
+        const uint32_t seg = item / strips, strip = item - seg * strips;
+        for (uint32_t r = 0; r < 32; ++r)
+            for (int s = 0; s < NSTRIP; ++s) {
+                const size_t col = ((size_t)strip * NSTRIP + s) * 64 + lane;
+                if (col < (size_t)W)
+                    __builtin_nontemporal_store(v4u{1, 2, 3, 4}, reinterpret_cast<v4u*>(out + (size_t)(seg * 32 + r) * ROWB + col * 16));
+            }
+    }
+}
+
+template <class F>
+static void timeit(const char* name, F launch)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 20; ++i) launch();
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 50; ++i) launch();
+    (void)hipEventRecord(e1, 0);
+    (void)hipDeviceSynchronize();
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    ms /= 50;
+    printf("%-8s %.4f ms  %.2f TB/s\n", name, ms, (double)ROWB * H / ms / 1e9);
+}
+
+int main()
+{
+    unsigned char* buf;
+    (void)hipMalloc(&buf, ROWB * H);
+    hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
+    const int grid = p.multiProcessorCount * 5;
+    timeit("linear", [&] { hipLaunchKernelGGL(k_linear, dim3(grid), dim3(256), 0, 0, buf, ROWB * H / 1024); });
+    timeit("strips", [&] { hipLaunchKernelGGL(k_strips<1>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("strips2", [&] { hipLaunchKernelGGL(k_strips<2>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("strips4", [&] { hipLaunchKernelGGL(k_strips<4>, dim3(grid), dim3(256), 0, 0, buf); });
+    return 0;
+}
