@@ -272,6 +272,51 @@ int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_fo
 /* An editor that owns edit state + device LUTs/masks for a row tile but no image. */
 int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_editor** out);
 
+/* ---- row-tile sharding of ONE frame over the GPUs of a node -----------------------------------
+ * Replaces the single dispatch of GpuProcessor::apply_adjustments (gpu_image_processing.rs:385-391; callers
+ * photo-editor-web/src/lib.rs:198, photo-editor-godot/src/lib.rs:257-271) when a frame is cut into contiguous row bands, one
+ * per process and GPU: with lens_distortion = 0 a pixel needs its own sample and a 5x5 CFA neighbourhood, so a band needs
+ * the two Bayer rows above and below it from its neighbours and nothing else.  An rpf_shard is one rank's end of that
+ * exchange: an RCCL communicator (librccl is loaded at rpf_shard_create, not linked: a single-GPU host never touches it),
+ * a side stream and two events.  One call per frame, rpf_shard_develop, enqueues the whole step and returns:
+ *
+ *     stream:  gate ----> fused kernel, interior rows (they read no halo row) ------------------> wait(done)
+ *     side:    wait(gate) -> ncclGroupStart, ncclSend/ncclRecv of the 2-row halos with the ranks above and below,
+ *              ncclGroupEnd -> fused kernel, the band's first and last 8 rows (one launch) -> done
+ *
+ * so the exchange (xGMI latency, not bandwidth: 2 x 2 x width bytes per direction) hides behind the interior.  The band
+ * buffer has the layout of rpf_dev_develop: (rows + 4) rows, row r = frame row y0 - 2 + r; the exchange writes rows 0, 1
+ * and rows + 2, rows + 3 (never at a frame edge: the kernel mirrors there) and sends rows 2, 3 and rows, rows + 1.  The
+ * editor is the band's (rpf_editor_create_for_tile with the band's y0 / rows; masks are band-sized).  Bands shorter than
+ * 32 rows are developed by one launch after the exchange.  lens_distortion != 0 does not shard (whole-frame resample):
+ * refused, as by rpf_dev_develop.
+ *
+ * rpf_shard_unique_id: ncclGetUniqueId — call on ONE rank and hand the 128 bytes to the others (any channel: a file, a
+ * socket, MPI, torch.distributed).  rpf_shard_create is collective (ncclCommInitRank): every rank of `world` calls it with
+ * the same id.  world = 1 is valid and needs no id (NULL): no communicator, rpf_shard_develop is a plain launch unless
+ * neighbours are set.  rpf_shard_set_neighbours overrides the ranks above / below (default rank - 1 / rank + 1, -1 = frame
+ * edge); up = down = rank makes a rank exchange with itself (its first rows land in its own top halo, its last rows in its
+ * bottom halo): the one-GPU rehearsal of the whole schedule, RCCL included. */
+#define RPF_SHARD_ID_BYTES 128
+typedef struct rpf_shard rpf_shard;
+enum {
+    RPF_SHARD_NO_EXCHANGE = 1u, /* halo rows are already in place (the caller exchanged or pre-filled them) */
+    RPF_SHARD_NO_OVERLAP = 2u,  /* exchange on `stream`, then ONE launch over the band */
+    RPF_SHARD_FORCE_SPLIT = 4u  /* interior / edges schedule even without neighbours (measuring its cost on one GPU) */
+};
+int rpf_shard_unique_id(uint8_t id[RPF_SHARD_ID_BYTES]);
+int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, rpf_shard** out);
+void rpf_shard_destroy(rpf_shard* s);
+int rpf_shard_set_neighbours(rpf_shard* s, int up, int down);
+/* rank / world / neighbours as the communicator sees them, and the PCI bus id of the shard's device ("0000:05:00.0") */
+int rpf_shard_info(const rpf_shard* s, int* rank, int* world, int* up, int* down, char* pci_bus_id, size_t len);
+/* the halo exchange alone, on `stream` (row_bytes = bytes of one band row; rows = band rows without the halos) */
+int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream);
+/* One frame step of this rank.  bits = 0: d_band is the u16 band (row_stride ignored); bits in {10, 12, 14, 16}: packed
+ * rows as in rpf_dev_develop_packed (their halo rows are packed rows too). */
+int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
+                      const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags);
+
 /* Kernel variant selection for A/B measurements (bench.py --variant); 0 = shipped configuration.
  * fused develop: 1 = LDS-tile front end (first design), 2 = 512-thread workgroups, 3 = pixel pair sequentially,
  * 6 = 4 instead of 5 waves per SIMD, 7 = the general multi-mask kernel also when only "main" exists,

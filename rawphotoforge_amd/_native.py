@@ -36,6 +36,8 @@ CFA_RGGB, CFA_BGGR, CFA_GRBG, CFA_GBRG = 0, 1, 2, 3
 FLAVOUR_ACTIVE, FLAVOUR_GODOT_LEGACY = 0, 1
 PACK_MSB_FIRST, PACK_LSB_FIRST, PACK_MIPI = 0, 1, 2
 CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
+SHARD_ID_BYTES = 128
+SHARD_NO_EXCHANGE, SHARD_NO_OVERLAP, SHARD_FORCE_SPLIT = 1, 2, 4
 
 
 class RawParams(C.Structure):
@@ -114,6 +116,14 @@ SYMBOLS = {
     "rpf_dev_develop_packed": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp]),
     "rpf_dev_apply": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "rpf_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+    "rpf_shard_unique_id": (C.c_int, [_P(C.c_uint8)]),
+    "rpf_shard_create": (C.c_int, [_vp, _P(C.c_uint8), C.c_int, C.c_int, _P(_vp)]),
+    "rpf_shard_destroy": (None, [_vp]),
+    "rpf_shard_set_neighbours": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "rpf_shard_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int), _P(C.c_int), C.c_char_p, _sz]),
+    "rpf_shard_exchange": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _vp]),
+    "rpf_shard_develop": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp,
+                                    C.c_uint32]),
 }
 
 _lib = None

@@ -22,9 +22,10 @@ LIB = os.path.join(HERE, "librpf_hip.so")
 UNITS = [("rpf_kernels.hip", "rpf_kernels_stream.o", ["-DRPF_TU=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
          ("rpf_kernels.hip", "rpf_kernels_rest.o", ["-DRPF_TU=2"]),
          ("rpf_api.cpp", "rpf_api.o", []),
+         ("rpf_shard.cpp", "rpf_shard.o", []),
          ("rpf_tables.cpp", "rpf_tables.o", [])]
 SOURCES = sorted({u[0] for u in UNITS})
-HEADERS = ["rpf_math.h", "rpf_chain.h", "rpf_host.h", "rpf_launch.h", os.path.join("..", "..", "include", "rpf.h")]
+HEADERS = ["rpf_math.h", "rpf_chain.h", "rpf_host.h", "rpf_launch.h", "rpf_internal.h", os.path.join("..", "..", "include", "rpf.h")]
 ARCH = "gfx950"
 
 
@@ -48,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.run(cmd, check=True)
     return LIB
 

@@ -10,8 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "rpf_host.h"
-#include "rpf_launch.h"
+#include "rpf_internal.h"
 
 namespace rpf {
 void build_math_tables(MathTables& T);
@@ -55,6 +54,10 @@ static int fail_exception() noexcept
         return RPF_ERR_GPU_COMPUTE;
     }
 }
+namespace rpf {
+int api_fail(int code, const std::string& msg) { return fail(code, msg); }
+int api_hip_fail(hipError_t e, const char* what) { return hip_fail(e, what); }
+}  // namespace rpf
 #define RPF_GUARDED(...)   \
     try {                  \
         __VA_ARGS__        \
@@ -68,19 +71,6 @@ static int fail_exception() noexcept
         if (_e != hipSuccess) return hip_fail(_e, #expr);    \
     } while (0)
 
-struct rpf_processor {
-    int device = 0;
-    int num_cus = 0;
-    int variant = 0;
-    MathTables* d_tabs = nullptr;
-    LegacyTables* d_legacy = nullptr;  // Godot-legacy flavour only
-    HueBound* d_hue_bounds = nullptr;  // 65536 entries, 1 MiB
-    HueBoundCs* d_hue_cs = nullptr;    // 65536 entries, 2 MiB (HUE_DIRECT launches)
-    // Arc<GpuProcessor> (lib.rs:83): one reference for the caller's handle plus one per editor created on it.
-    // rpf_processor_destroy drops the caller's; the device tables are freed by whoever drops the last one.
-    std::atomic<int> refs{1};
-};
-
 static void processor_unref(rpf_processor* p)
 {
     if (p->refs.fetch_sub(1) != 1) return;
@@ -93,41 +83,9 @@ static void processor_unref(rpf_processor* p)
     delete p;
 }
 
-struct CurveStamps {
-    uint64_t v[4];
-};
-
-struct rpf_editor {
-    rpf_processor* proc = nullptr;  // null: headless (state only)
-    EditState state;
-    TileGeom geom{};
-    bool owns_image = false;      // created from host pixels (vs. for_tile)
-    bool is_bayer = false;
-    int flavour = RPF_FLAVOUR_ACTIVE;
-    RawParamsDev raw{};
-    uint16_t* d_cfa = nullptr;    // (rows + 4) x width, rows 0,1 and rows+2,rows+3 are halo
-    float* d_original = nullptr;  // RGBA32F linear (rgb editors; bayer editors: demosaic cache)
-    bool original_valid = false;
-    float* d_image = nullptr;     // RGBA32F result of the last apply
-    bool image_valid = false;
-    void* d_scratch = nullptr;    // readback repack
-    size_t scratch_bytes = 0;
-    // device copy of the edit state
-    uint16_t* d_bright = nullptr;
-    ushort4* d_hsl = nullptr;
-    uint8_t* d_masks = nullptr;       // user-mask planes as uploaded (u8, binarised)
-    uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
-    uint32_t lut_capacity = 0;    // masks worth of LUT storage
-    uint32_t mask_capacity = 0;   // user-mask planes allocated
-    uint64_t uploaded_params = 0, uploaded_masks = 0;
-    std::vector<CurveStamps> uploaded_curves;  // per mask slot: EditParameters::curve_ver of what the device holds
-    DeviceEdit dev{};
-    hipStream_t stream = nullptr;
-
-    rpf_editor(uint32_t w, uint32_t h) : state(w, h) {}
-};
-
-static LaunchCfg cfg_of(const rpf_processor* p) { return LaunchCfg{p->num_cus, p->variant}; }
+namespace rpf {
+void api_processor_unref(rpf_processor* p) { processor_unref(p); }
+}  // namespace rpf
 
 static size_t npix_of(const rpf_editor* e) { return (size_t)e->geom.rows * e->geom.width; }
 
@@ -137,6 +95,9 @@ static int sync_edit_state(rpf_editor* e)
 {
     RPF_GUARDED(return sync_edit_state_impl(e);)
 }
+namespace rpf {
+int api_sync_edit_state(rpf_editor* e) { return sync_edit_state(e); }
+}  // namespace rpf
 static int sync_edit_state_impl(rpf_editor* e)
 {
     const uint32_t n = (uint32_t)e->state.masks.size();

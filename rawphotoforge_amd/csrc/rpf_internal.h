@@ -1,0 +1,70 @@
+// rpf_internal.h — what the translation units behind include/rpf.h share: the two handle types and the error plumbing.
+// Not installed, not part of the ABI.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <string>
+#include <vector>
+
+#include "rpf_host.h"
+#include "rpf_launch.h"
+
+struct rpf_processor {
+    int device = 0;
+    int num_cus = 0;
+    int variant = 0;
+    rpf::MathTables* d_tabs = nullptr;
+    rpf::LegacyTables* d_legacy = nullptr;  // Godot-legacy flavour only
+    rpf::HueBound* d_hue_bounds = nullptr;  // 65536 entries, 1 MiB
+    rpf::HueBoundCs* d_hue_cs = nullptr;    // 65536 entries, 2 MiB (HUE_DIRECT launches)
+    // Arc<GpuProcessor> (lib.rs:83): one reference for the caller's handle plus one per editor created on it.
+    // rpf_processor_destroy drops the caller's; the device tables are freed by whoever drops the last one.
+    std::atomic<int> refs{1};
+};
+
+struct CurveStamps {
+    uint64_t v[4];
+};
+
+struct rpf_editor {
+    rpf_processor* proc = nullptr;  // null: headless (state only)
+    rpf::EditState state;
+    rpf::TileGeom geom{};
+    bool owns_image = false;      // created from host pixels (vs. for_tile)
+    bool is_bayer = false;
+    int flavour = RPF_FLAVOUR_ACTIVE;
+    rpf::RawParamsDev raw{};
+    uint16_t* d_cfa = nullptr;    // (rows + 4) x width, rows 0,1 and rows+2,rows+3 are halo
+    float* d_original = nullptr;  // RGBA32F linear (rgb editors; bayer editors: demosaic cache)
+    bool original_valid = false;
+    float* d_image = nullptr;     // RGBA32F result of the last apply
+    bool image_valid = false;
+    void* d_scratch = nullptr;    // readback repack
+    size_t scratch_bytes = 0;
+    // device copy of the edit state
+    uint16_t* d_bright = nullptr;
+    ushort4* d_hsl = nullptr;
+    uint8_t* d_masks = nullptr;       // user-mask planes as uploaded (u8, binarised)
+    uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
+    uint32_t lut_capacity = 0;    // masks worth of LUT storage
+    uint32_t mask_capacity = 0;   // user-mask planes allocated
+    uint64_t uploaded_params = 0, uploaded_masks = 0;
+    std::vector<CurveStamps> uploaded_curves;  // per mask slot: EditParameters::curve_ver of what the device holds
+    rpf::DeviceEdit dev{};
+    hipStream_t stream = nullptr;
+
+    rpf_editor(uint32_t w, uint32_t h) : state(w, h) {}
+};
+
+
+namespace rpf {
+// thread-local rpf_last_error() text + the status code, for every translation unit of the library
+int api_fail(int code, const std::string& msg);
+int api_hip_fail(hipError_t e, const char* what);
+// refresh the device copy of params / curves / masks if a setter ran since the last upload (rpf_api.cpp)
+int api_sync_edit_state(rpf_editor* e);
+// Arc<GpuProcessor>: drop one reference (the device tables go with the last one)
+void api_processor_unref(rpf_processor* p);
+inline LaunchCfg cfg_of(const rpf_processor* p) { return LaunchCfg{p->num_cus, p->variant}; }
+}  // namespace rpf

@@ -79,11 +79,11 @@ __device__ __forceinline__ MaskParams mask_params_user(const LdsMaskParams& s, u
     P.sat_gain = bits2f(q2.z); P.light_gain = bits2f(q2.w);
     return P;
 }
-__device__ __forceinline__ void stage_mask_params(const DeviceEdit& ed, unsigned char* lds, int tid)
+__device__ __forceinline__ void stage_mask_params(const DeviceEdit& ed, unsigned char* lds, int tid, int nt)
 {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(ed.mp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
-    if (tid < (int)(sizeof(MaskParams) * RPF_MAX_MASKS / 4)) dst[tid] = src[tid];
+    for (int i = tid; i < (int)(sizeof(MaskParams) * RPF_MAX_MASKS / 4); i += nt) dst[i] = src[i];
 }
 
 // The dynamic shared block must start at LDS address 0 for LdsTabs' constant addresses to be right (it does: these
@@ -336,9 +336,12 @@ struct StreamArgs {
     // Items [0, tail_start) are dealt whole.  The last, incomplete round — fewer items than waves — is cut into
     // single-pair sub-items: virtual item tail_start + t is pair (t % seg_pairs) of item tail_start + t / seg_pairs.
     uint32_t tail_start, nvirt;
-    // PACKED input (rpf_dev_develop_packed): cfa points at MSB-first bit-packed rows instead of a u16 plane
+    // PACKED input (rpf_dev_develop_packed): cfa points at bit-packed rows (any of the three orders below) instead of a u16 plane
     uint32_t bits, row_stride, row_bytes;  // sample width; bytes between rows; bytes of one row = ceil(W * bits / 8)
     uint32_t lsb;                          // 0 = MSB-first bit stream, 1 = LSB-first (little-endian), 2 = MIPI CSI-2 groups
+    // PART_EDGES launches (row-tile sharding): segments from skip_from on lie skip_pairs row pairs further down, so one
+    // launch covers the band's first and last rows and nothing in between (skip_from = ~0: no gap)
+    uint32_t skip_from, skip_pairs;
 };
 
 // One CFA row of a strip as the wavefront sees it: v = this lane's sample; p1 / p2 = the W+E sums at
@@ -375,7 +378,7 @@ void k_stream(const StreamArgs a)
     if (MODE != MODE_DEMOSAIC) {
         assert_lds_base(smem);
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
-        if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid);
+        if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
@@ -424,7 +427,7 @@ void k_stream(const StreamArgs a)
         }
         const uint32_t seg = item / a.strips, strip = item - seg * a.strips;
         const int x0 = (int)strip * STRIP_W;
-        const int pair0 = (int)(seg * a.seg_pairs + sub);
+        const int pair0 = (int)(seg * a.seg_pairs + sub + (seg >= a.skip_from ? a.skip_pairs : 0u));
         const int npairs = min((int)sub_pairs, total_pairs - pair0);
         if (npairs <= 0) continue;  // sub-item past the end of a ragged last segment
         const int xl = x0 + lane;  // this lane's column
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     assert_lds_base(smem);
     stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
-    if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid);
+    if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
     const LdsTabs tabs(0u, T);
@@ -1052,6 +1055,24 @@ static hipError_t check_edit(const DeviceEdit& ed)
 }
 
 #if RPF_TU != 2
+// PART_INTERIOR (rpf_launch.h): the rows of tile `g` that PART_EDGES leaves out, as a tile of their own — the first
+// 2 * EDGE_PAIRS rows and the last EDGE_PAIRS row pairs removed; skip_px = the pixels in front of it (input rows, output
+// pixels and the mask-bit plane all start that much further on).
+static size_t out_bytes(int out_format) { return out_format == OUT_RGBA_F32 ? 16 : (out_format == OUT_RGB_F32 ? 12 : 3); }
+static hipError_t interior_of(const TileGeom& g, const DeviceEdit& ed, int out_format, TileGeom& gi, DeviceEdit& edi,
+                              size_t& skip_px)
+{
+    const uint32_t total_pairs = (g.rows + 1) / 2;
+    if (g.rows < 4 * 2 * EDGE_PAIRS) return hipErrorInvalidValue;  // no interior worth a launch of its own
+    if (out_format != OUT_RGBA_F32 && out_format != OUT_RGB_F32 && out_format != OUT_RGB_U8) return hipErrorInvalidValue;
+    const uint32_t first = 2 * EDGE_PAIRS, end = 2 * (total_pairs - EDGE_PAIRS);
+    gi = TileGeom{g.width, g.height, g.y0 + first, end - first};
+    edi = ed;
+    skip_px = (size_t)first * g.width;
+    if (ed.mask_bits) edi.mask_bits = ed.mask_bits + skip_px;
+    return hipSuccess;
+}
+
 struct PackedRows {  // bit-packed input of the fused kernel (bits == 0: d_cfa is a u16 plane)
     uint32_t bits, row_stride, lsb;
 };
@@ -1063,6 +1084,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
 {
     StreamArgs a;
     memset(&a, 0, sizeof(a));
+    a.skip_from = 0xffffffffu;
     a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
     a.bits = pk.bits; a.row_stride = pk.row_stride; a.lsb = pk.lsb;
     a.row_bytes = (uint32_t)(((uint64_t)g.width * pk.bits + 7) / 8);
@@ -1123,6 +1145,14 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
         }
     }
     a.nitems = items_for(a.seg_pairs);
+    if (cfg.part == PART_EDGES) {  // PART_EDGES: two segments of EDGE_PAIRS row pairs, the first and the last of the band (rpf_launch.h)
+        if (total_pairs < 2 * EDGE_PAIRS) return hipErrorInvalidValue;
+        a.seg_pairs = EDGE_PAIRS;
+        a.nitems = a.strips * 2;
+        a.skip_from = 1;
+        a.skip_pairs = total_pairs - 2 * EDGE_PAIRS;
+        whole_rounds = true;  // no tail splitting: at most one item per wave
+    }
     uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
     a.tail_start = a.nvirt = a.nitems;
     if (MODE != MODE_DEMOSAIC) {
@@ -1254,6 +1284,17 @@ hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, 
     if (row_stride < need) return hipErrorInvalidValue;
     if ((uint64_t)row_stride * (g.rows + 4) > 0xffffffffull) return hipErrorInvalidValue;  // 32-bit row offsets
     if (ed.lens_strength != 0.0f || ed.flags != 0) return hipErrorInvalidValue;
+    if (cfg.part == PART_INTERIOR) {
+        TileGeom gi;
+        DeviceEdit edi;
+        size_t skip_px;
+        if ((e = interior_of(g, ed, out_format, gi, edi, skip_px)) != hipSuccess) return e;
+        LaunchCfg ci = cfg;
+        ci.part = PART_ALL;
+        return launch_develop_packed(ci, d_packed + (skip_px / g.width) * row_stride, row_stride, bits, order, raw, gi, edi,
+                                     reinterpret_cast<unsigned char*>(d_out) + skip_px * out_bytes(out_format), out_format, s);
+    }
+    if (cfg.part == PART_EDGES && g.rows < 4 * EDGE_PAIRS) return hipErrorInvalidValue;
     const PackedRows pk{bits, row_stride, order};
     switch (out_format) {
     // the CSI-2 group layout is a compile-time variant of the packed row loads (as a run-time branch per sample it cost
@@ -1277,6 +1318,17 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
     if (!d_cfa || !d_out) return hipErrorInvalidValue;
     if (ed.lens_strength != 0.0f) return hipErrorInvalidValue;  // needs the resampling pass (launch_apply)
     if (ed.flags != 0) return hipErrorInvalidValue;             // the Godot-legacy flavour lives in k_apply only
+    if (cfg.part == PART_INTERIOR) {  // the rows between the two edge segments, as a tile of their own
+        TileGeom gi;
+        DeviceEdit edi;
+        size_t skip_px;
+        if ((e = interior_of(g, ed, out_format, gi, edi, skip_px)) != hipSuccess) return e;
+        LaunchCfg ci = cfg;
+        ci.part = PART_ALL;
+        return launch_develop(ci, d_cfa + skip_px, raw, gi, edi, reinterpret_cast<unsigned char*>(d_out) + skip_px * out_bytes(out_format),
+                              out_format, s);
+    }
+    if (cfg.part == PART_EDGES && g.rows < 4 * EDGE_PAIRS) return hipErrorInvalidValue;
     switch (out_format) {
     case OUT_RGBA_F32: return develop_fmt<OUT_RGBA_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
     case OUT_RGB_F32: return develop_fmt<OUT_RGB_F32>(cfg, d_cfa, raw, g, ed, d_out, s);

@@ -34,9 +34,17 @@ struct TileGeom {
 
 enum OutFormat { OUT_RGBA_F32 = 0, OUT_RGB_F32 = 1, OUT_RGB_U8 = 2 };
 
+// Which rows of its tile a fused launch develops (row-tile sharding, rpf_shard.cpp).  PART_EDGES: the first
+// 2 * EDGE_PAIRS rows and everything from row 2 * ((rows + 1) / 2 - EDGE_PAIRS) on — the rows whose 5x5 neighbourhoods
+// reach the band's halo rows — in ONE launch; PART_INTERIOR: the rows in between, which read no halo row.  Together
+// they write every pixel of the tile exactly once, with the bits of a PART_ALL launch.  A tile needs 32 rows for either.
+enum RowPart { PART_ALL = 0, PART_INTERIOR = 1, PART_EDGES = 2 };
+constexpr uint32_t EDGE_PAIRS = 4;
+
 struct LaunchCfg {
     int num_cus;
     int variant;  // 0 default; see rpf_kernels.hip
+    int part = PART_ALL;  // fused develop launches only
 };
 
 // d_cfa: (rows + 4) x width u16, row r = frame row y0 - 2 + r
@@ -45,14 +53,15 @@ hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const Ra
 hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                           const DeviceEdit& ed, void* d_out, int out_format, hipStream_t s);
 // the same with the integer unpack folded in: d_packed holds (rows + 4) bit-packed rows (10/12/14/16 bits), `order` =
-// RPF_PACK_MSB_FIRST (big-endian bit stream), RPF_PACK_LSB_FIRST (little-endian) or RPF_PACK_MIPI (CSI-2 groups; unpack only)
+// RPF_PACK_MSB_FIRST (big-endian bit stream), RPF_PACK_LSB_FIRST (little-endian) or RPF_PACK_MIPI (CSI-2 groups: rows need
+// row_stride >= 8 readable bytes, the kernel reads a group through an 8-byte window); all three inside the fused kernel
 hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, uint32_t row_stride, uint32_t bits,
                                  uint32_t order, const RawParamsDev& raw, const TileGeom& g, const DeviceEdit& ed, void* d_out,
                                  int out_format, hipStream_t s);
 // d_in: rows x width RGBA32F (whole frame when lens_strength != 0)
 hipError_t launch_apply(const LaunchCfg& cfg, const float* d_in, const TileGeom& g, const DeviceEdit& ed, void* d_out,
                         int out_format, hipStream_t s);
-// packed RAW (10/12/14/16 bits, MSB-first or LSB-first bit stream per `order`) -> u16 plane of pitch `width`
+// packed RAW (10/12/14/16 bits; MSB-first or LSB-first bit stream, or MIPI CSI-2 RAW10/12/14 groups, per `order`) -> u16 plane of pitch `width`
 hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t width, uint32_t rows, uint32_t bits,
                          uint32_t order, uint16_t* d_out, hipStream_t s);
 // streaming read of a freshly written buffer (lands it in the Infinity Cache ahead of the fused kernel)

@@ -1,0 +1,312 @@
+// rpf_shard.cpp — one rank's end of the row-tile sharding of ONE frame over the GPUs of a node (include/rpf.h,
+// "row-tile sharding").  Replaces the single dispatch of gpu_image_processing.rs:385-391 where the
+// frame is cut into row bands, one process and GPU per band.
+//
+// MI355X-first: xGMI is point-to-point and a halo is 2 rows (24-48 KB), so the exchange is latency, not bandwidth.  It is
+// one ncclGroup of neighbour sends / receives on a high-priority side stream, issued BEFORE the interior launch so that
+// RCCL's few workgroups get their CU slots ahead of the fused kernel's persistent ones, and the rows that need the halos
+// (first and last 8 of the band) are ONE small launch behind it.  Everything a step needs is enqueued by one C call:
+// no Python, no per-step allocation, no host synchronisation.
+//
+// librccl is loaded with dlopen at rpf_shard_create (world > 1, or a self-exchange rehearsal): librpf_hip.so does not
+// link it, so a single-GPU host (the reference's only configuration) never maps the 300-MB library.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enumerators only: every entry point is resolved with dlsym
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "rpf_internal.h"
+
+using namespace rpf;
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    std::string path, error;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// One RCCL per process.  A library that is already mapped under the SONAME librccl.so.1 (a ROCm PyTorch wheel brings
+// its own) is what dlopen returns for that name, so the process never holds two.
+const Rccl* rccl()
+{
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("RPF_RCCL_LIB");
+        const char* cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* c : cands) {
+            if (!c || !*c) continue;
+            R.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+            if (R.handle) { R.path = c; break; }
+            const char* de = dlerror();
+            R.error += std::string(R.error.empty() ? "" : "; ") + c + ": " + (de ? de : "?");
+        }
+        if (!R.handle) return;
+        bool all = true;
+        auto sym = [&](const char* name) {
+            void* p = dlsym(R.handle, name);
+            if (!p) { all = false; R.error += std::string(" missing symbol ") + name; }
+            return p;
+        };
+        R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
+        R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
+        R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+        R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
+        R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
+        R.Send = reinterpret_cast<decltype(R.Send)>(sym("ncclSend"));
+        R.Recv = reinterpret_cast<decltype(R.Recv)>(sym("ncclRecv"));
+        R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!all) { dlclose(R.handle); R.handle = nullptr; }
+    });
+    return R.handle ? &R : nullptr;
+}
+
+int rccl_missing()
+{
+    return api_fail(RPF_ERR_GPU_INITIALIZATION, "GPU initialization error: librccl could not be loaded for the halo exchange");
+}
+
+int nccl_fail(const Rccl* R, ncclResult_t r, const char* what, int code = RPF_ERR_GPU_COMPUTE)
+{
+    return api_fail(code, std::string(code == RPF_ERR_GPU_INITIALIZATION ? "GPU initialization error: " : "GPU compute error: ") +
+                              what + ": " + (R && R->GetErrorString ? R->GetErrorString(r) : "RCCL error"));
+}
+
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return api_hip_fail(_e, #expr); \
+    } while (0)
+#define NCCL_TRY(R, expr)                                        \
+    do {                                                         \
+        ncclResult_t _r = (expr);                                \
+        if (_r != ncclSuccess) return nccl_fail(R, _r, #expr);   \
+    } while (0)
+
+}  // namespace
+
+struct rpf_shard {
+    rpf_processor* proc = nullptr;
+    int rank = 0, world = 1;
+    int up = -1, down = -1;  // ranks that hold the rows above / below this band; -1 = frame edge
+    ncclComm_t comm = nullptr;
+    hipStream_t side = nullptr;            // exchange + edge rows (highest priority)
+    hipEvent_t gate = nullptr, done = nullptr;
+    char bus[32] = {0};
+};
+
+namespace {
+
+int need_comm(rpf_shard* s)
+{
+    if (s->comm) return RPF_OK;
+    // a self-exchange on a shard created without an id (world = 1): a one-rank communicator of its own
+    const Rccl* R = rccl();
+    if (!R) return rccl_missing();
+    if (s->world != 1) return api_fail(RPF_ERR_INVALID_ARGUMENT, "shard has no communicator");
+    ncclUniqueId id;
+    ncclResult_t r = R->GetUniqueId(&id);
+    if (r == ncclSuccess) r = R->CommInitRank(&s->comm, 1, id, 0);
+    if (r != ncclSuccess) return nccl_fail(R, r, "ncclCommInitRank(1 rank)", RPF_ERR_GPU_INITIALIZATION);
+    return RPF_OK;
+}
+
+// The 2-row halos of `band` with the ranks above and below, as one group on `stream`.
+int enqueue_exchange(rpf_shard* s, unsigned char* band, size_t row_bytes, uint32_t rows, hipStream_t stream)
+{
+    if (s->up < 0 && s->down < 0) return RPF_OK;
+    if (rows < 2) return api_fail(RPF_ERR_INVALID_ARGUMENT, "a band must have at least 2 rows to feed its neighbours' halos");
+    int rc = need_comm(s);
+    if (rc) return rc;
+    const Rccl* R = rccl();
+    const size_t n = 2 * row_bytes;  // RCCL has no 16-bit integer type: the rows travel as bytes
+    NCCL_TRY(R, R->GroupStart());
+    ncclResult_t r = ncclSuccess;
+    if (s->up >= 0) {  // my first two rows are the bottom halo of the rank above
+        r = R->Send(band + 2 * row_bytes, n, ncclUint8, s->up, s->comm, stream);
+        if (r == ncclSuccess) r = R->Recv(band, n, ncclUint8, s->up, s->comm, stream);
+    }
+    if (r == ncclSuccess && s->down >= 0) {
+        r = R->Send(band + (size_t)rows * row_bytes, n, ncclUint8, s->down, s->comm, stream);
+        if (r == ncclSuccess) r = R->Recv(band + ((size_t)rows + 2) * row_bytes, n, ncclUint8, s->down, s->comm, stream);
+    }
+    const ncclResult_t rg = R->GroupEnd();  // always closed, also after a failed call inside it
+    if (r != ncclSuccess) return nccl_fail(R, r, "ncclSend/ncclRecv(halo rows)");
+    if (rg != ncclSuccess) return nccl_fail(R, rg, "ncclGroupEnd(halo rows)");
+    return RPF_OK;
+}
+
+struct BandLaunch {
+    rpf_editor* e;
+    const unsigned char* band;
+    uint32_t row_stride, bits, order;
+    RawParamsDev raw;
+    void* out;
+    int out_format;
+};
+
+hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream)
+{
+    LaunchCfg cfg = cfg_of(b.e->proc);
+    cfg.part = part;
+    if (b.bits)
+        return launch_develop_packed(cfg, b.band, b.row_stride, b.bits, b.order, b.raw, b.e->geom, b.e->dev, b.out, b.out_format,
+                                     stream);
+    return launch_develop(cfg, reinterpret_cast<const uint16_t*>(b.band), b.raw, b.e->geom, b.e->dev, b.out, b.out_format, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpf_shard_unique_id(uint8_t id[RPF_SHARD_ID_BYTES])
+{
+    static_assert(RPF_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id is an ncclUniqueId");
+    if (!id) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null id");
+    const Rccl* R = rccl();
+    if (!R) return rccl_missing();
+    ncclUniqueId u;
+    const ncclResult_t r = R->GetUniqueId(&u);
+    if (r != ncclSuccess) return nccl_fail(R, r, "ncclGetUniqueId", RPF_ERR_GPU_INITIALIZATION);
+    memcpy(id, u.internal, RPF_SHARD_ID_BYTES);
+    return RPF_OK;
+}
+
+void rpf_shard_destroy(rpf_shard* s)
+{
+    if (!s) return;
+    if (s->proc && hipSetDevice(s->proc->device) == hipSuccess) {
+        if (s->side) (void)hipStreamSynchronize(s->side);
+        const Rccl* R = s->comm ? rccl() : nullptr;
+        if (R) (void)R->CommDestroy(s->comm);
+        if (s->gate) (void)hipEventDestroy(s->gate);
+        if (s->done) (void)hipEventDestroy(s->done);
+        if (s->side) (void)hipStreamDestroy(s->side);
+    }
+    if (s->proc) api_processor_unref(s->proc);
+    delete s;
+}
+
+int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, rpf_shard** out)
+{
+    if (!p || !out) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return api_fail(RPF_ERR_INVALID_ARGUMENT, "rank outside [0, world)");
+    if (world > 1 && !id) return api_fail(RPF_ERR_INVALID_ARGUMENT, "a shard of more than one rank needs the unique id");
+    rpf_shard* s = new (std::nothrow) rpf_shard;
+    if (!s) return api_fail(RPF_ERR_GPU_INITIALIZATION, "out of host memory");
+    s->proc = p;
+    p->refs.fetch_add(1);
+    s->rank = rank;
+    s->world = world;
+    s->up = rank > 0 ? rank - 1 : -1;
+    s->down = rank < world - 1 ? rank + 1 : -1;
+    auto bail = [&](int rc) { rpf_shard_destroy(s); return rc; };
+    hipError_t he = hipSetDevice(p->device);
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (he == hipSuccess) he = hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, hi);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->gate, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipDeviceGetPCIBusId(s->bus, (int)sizeof(s->bus), p->device);
+    if (he != hipSuccess) return bail(api_hip_fail(he, "shard stream / events"));
+    if (world > 1) {
+        const Rccl* R = rccl();
+        if (!R) return bail(rccl_missing());
+        ncclUniqueId u;
+        memcpy(u.internal, id, RPF_SHARD_ID_BYTES);
+        const ncclResult_t r = R->CommInitRank(&s->comm, world, u, rank);
+        if (r != ncclSuccess) return bail(nccl_fail(R, r, "ncclCommInitRank", RPF_ERR_GPU_INITIALIZATION));
+    }
+    *out = s;
+    return RPF_OK;
+}
+
+int rpf_shard_set_neighbours(rpf_shard* s, int up, int down)
+{
+    if (!s) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null shard");
+    if (up < -1 || up >= s->world || down < -1 || down >= s->world)
+        return api_fail(RPF_ERR_INVALID_ARGUMENT, "neighbour outside [-1, world)");
+    s->up = up;
+    s->down = down;
+    return RPF_OK;
+}
+
+int rpf_shard_info(const rpf_shard* s, int* rank, int* world, int* up, int* down, char* pci_bus_id, size_t len)
+{
+    if (!s) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null shard");
+    if (rank) *rank = s->rank;
+    if (world) *world = s->world;
+    if (up) *up = s->up;
+    if (down) *down = s->down;
+    if (pci_bus_id && len) {
+        strncpy(pci_bus_id, s->bus, len - 1);
+        pci_bus_id[len - 1] = 0;
+    }
+    return RPF_OK;
+}
+
+int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream)
+{
+    if (!s || !d_band || row_bytes == 0) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(s->proc->device));
+    return enqueue_exchange(s, static_cast<unsigned char*>(d_band), row_bytes, rows, (hipStream_t)stream);
+}
+
+int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
+                      const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags)
+{
+    if (!s || !e || !d_band || !raw || !d_out) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!e->proc) return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: headless editor has no device (no CPU fallback exists)");
+    if (e->proc != s->proc) return api_fail(RPF_ERR_INVALID_ARGUMENT, "editor and shard belong to different processors");
+    if (order > RPF_PACK_MIPI) return api_fail(RPF_ERR_INVALID_ARGUMENT, "unknown bit order");
+    if (bits != 0 && bits != 10 && bits != 12 && bits != 14 && (bits != 16 || order == RPF_PACK_MIPI))
+        return api_fail(RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT, "Unsupported read image format: packed samples must be 10, 12, 14 or 16 bits");
+    const size_t row_bytes = bits ? row_stride : (size_t)e->geom.width * sizeof(uint16_t);
+    if (bits && (row_stride < ((size_t)e->geom.width * bits + 7) / 8 || row_stride > 0xffffffffu))
+        return api_fail(RPF_ERR_INVALID_ARGUMENT, "row_stride shorter than a packed row");
+    HIP_TRY(hipSetDevice(s->proc->device));
+    int rc = api_sync_edit_state(e);
+    if (rc) return rc;
+    if (e->dev.lens_strength != 0.0f)
+        return api_fail(RPF_ERR_INVALID_ARGUMENT, "lens distortion resamples the whole frame: it does not shard by rows");
+    if (e->flavour != RPF_FLAVOUR_ACTIVE)
+        return api_fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
+    e->dev.flags = 0;
+    hipStream_t cur = (hipStream_t)stream;
+    unsigned char* band = static_cast<unsigned char*>(d_band);
+    const BandLaunch b{e, band, (uint32_t)row_stride, bits, order, make_raw_params(*raw), d_out, out_format};
+    const uint32_t rows = e->geom.rows;
+    const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
+    const bool split = ((exchange && !(flags & RPF_SHARD_NO_OVERLAP)) || (flags & RPF_SHARD_FORCE_SPLIT)) &&
+                       rows >= 4 * 2 * EDGE_PAIRS;
+    if (!split) {
+        if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, cur))) return rc;
+        HIP_TRY(launch_part(b, PART_ALL, cur));
+        return RPF_OK;
+    }
+    // side stream: gated on what `cur` held before this step (the band's upload, the previous step's readers of the halo
+    // rows); the exchange goes first so that RCCL's workgroups are dispatched ahead of the interior's persistent ones
+    HIP_TRY(hipEventRecord(s->gate, cur));
+    HIP_TRY(hipStreamWaitEvent(s->side, s->gate, 0));
+    if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, s->side))) return rc;
+    HIP_TRY(launch_part(b, PART_INTERIOR, cur));
+    HIP_TRY(launch_part(b, PART_EDGES, s->side));
+    HIP_TRY(hipEventRecord(s->done, s->side));
+    HIP_TRY(hipStreamWaitEvent(cur, s->done, 0));
+    return RPF_OK;
+}
+
+}  // extern "C"

@@ -413,6 +413,60 @@ class PhotoEditor:
             pass
 
 
+class Shard:
+    """One rank's end of the row-tile sharding of a frame (include/rpf.h rpf_shard_*): an RCCL communicator over the
+    ranks of the node, a side stream and two events inside librpf_hip.so.  `unique_id()` on one rank, the 128 bytes to
+    the others by any channel, then `Shard(gpu, id, rank, world)` on every rank (collective)."""
+
+    def __init__(self, gpu_processor: GpuProcessor, unique_id: Optional[bytes], rank: int = 0, world: int = 1):
+        h = C.c_void_p()
+        idbuf = None
+        if unique_id is not None:
+            if len(unique_id) != N.SHARD_ID_BYTES:
+                raise InvalidArgument("the shard id is %d bytes" % N.SHARD_ID_BYTES)
+            idbuf = (C.c_uint8 * N.SHARD_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _check(N.lib().rpf_shard_create(gpu_processor._h, idbuf, rank, world, C.byref(h)))
+        self._h, self._proc = h, gpu_processor
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * N.SHARD_ID_BYTES)()
+        _check(N.lib().rpf_shard_unique_id(buf))
+        return bytes(buf)
+
+    def set_neighbours(self, up: int, down: int) -> None:
+        _check(N.lib().rpf_shard_set_neighbours(self._h, up, down))
+
+    def info(self) -> dict:
+        r, w, u, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        bus = C.create_string_buffer(64)
+        _check(N.lib().rpf_shard_info(self._h, C.byref(r), C.byref(w), C.byref(u), C.byref(d), bus, 64))
+        return {"rank": r.value, "world": w.value, "up": u.value, "down": d.value, "pci_bus_id": bus.value.decode()}
+
+    def exchange(self, d_band_ptr: int, row_bytes: int, rows: int, stream: int = 0) -> None:
+        _check(N.lib().rpf_shard_exchange(self._h, C.c_void_p(d_band_ptr), row_bytes, rows, C.c_void_p(stream)))
+
+    def develop(self, editor: "PhotoEditor", d_band_ptr: int, raw, d_out_ptr: int, out_format: int = N.OUT_RGBA_F32,
+                stream: int = 0, flags: int = 0, packed=None) -> None:
+        """One frame step of this rank: exchange + interior + edges enqueued by ONE library call.
+        packed = (bits, row_stride, order) for bit-packed band rows."""
+        rp = raw if isinstance(raw, N.RawParams) else raw.to_c()
+        bits, stride, order = packed if packed else (0, 0, 0)
+        _check(N.lib().rpf_shard_develop(self._h, editor._h, C.c_void_p(d_band_ptr), stride, bits, order, C.byref(rp),
+                                         C.c_void_p(d_out_ptr), out_format, C.c_void_p(stream), flags))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            N.lib().rpf_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def dev_demosaic(processor: GpuProcessor, d_cfa_ptr: int, raw: RawParams, frame_width: int, frame_height: int,
                  y0: int, rows: int, d_rgba_ptr: int, stream: int = 0) -> None:
     rp = raw.to_c()

@@ -218,3 +218,53 @@ class BandDeveloper:
             r.wait()
         launch(self.parts[1])
         launch(self.parts[2])
+
+
+class ShardedDeveloper:
+    """One rank's band through the library's own sharded step (include/rpf.h rpf_shard_develop): ONE C call per frame
+    enqueues the gate, the RCCL halo exchange on the library's side stream, the interior launch and the single
+    edge-rows launch.  The measured N > 1 configuration of bench.py; BandDeveloper (torch.distributed) remains as
+    the rehearsal path for gloo and as the fallback when RCCL cannot be initialised inside the library.
+
+    `shard`: a rawphotoforge_amd.Shard (None: a one-rank shard without neighbours is created).
+    `configure(ed)`: sets up the edit state of the band's editor; `add_mask` takes band-sized masks (rows x W).
+    """
+
+    def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, shard=None, packed=None,
+                 overlap=True, force_split=False):
+        from . import _native as N
+        from .editor import PhotoEditor, Shard
+
+        self.raw = raw.to_c() if hasattr(raw, "to_c") else raw
+        self.packed = packed  # (bits, row_stride_bytes, order)
+        self.shard = shard if shard is not None else Shard(gpu, None, 0, 1)
+        self.w, self.rows = frame_width, rows
+        self.ed = PhotoEditor.for_tile(gpu, frame_width, frame_height, y0, rows)
+        configure(self.ed)
+        self.flags = (0 if overlap else N.SHARD_NO_OVERLAP) | (N.SHARD_FORCE_SPLIT if force_split else 0)
+        self._no_exchange = N.SHARD_NO_EXCHANGE
+        info = self.shard.info()
+        neighbours = info["up"] >= 0 or info["down"] >= 0
+        self.split = ((neighbours and overlap) or force_split) and rows >= 32
+        # bench.py's accounting: (row offset, rows, editor) of the launch its kernel events would bracket
+        self.parts = [(8, rows - 16, self.ed)] if self.split else [(0, rows, self.ed)]
+
+    def join(self):
+        """rpf_shard_develop joins the side stream itself: nothing to do (BandDeveloper API compatibility)."""
+
+    def step(self, band, out, out_format=0, bytes_per_px=16, exchange=True, events=None, stream=None):
+        """band: (rows + 4, W) 2-byte tensor with halo rows (packed: (rows + 4, row_stride) uint8); out: rows x W pixels.
+        `events`: optional (start, end) CUDA events recorded on the launch stream around the WHOLE step (the interior
+        launch is inside the library call, so they also cover the wait for the edge rows)."""
+        if stream is None:
+            import torch
+            cur = torch.cuda.current_stream()
+            stream = cur.cuda_stream
+        else:
+            cur = None
+        if events and cur is not None:
+            events[0].record(cur)
+        self.shard.develop(self.ed, band.data_ptr(), self.raw, out.data_ptr(), out_format, stream,
+                           self.flags | (0 if exchange else self._no_exchange), self.packed)
+        if events and cur is not None:
+            events[1].record(cur)

@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 # modules that load librpf_hip.so (the product); the rest of the CPU suite — oracle known answers, the oracle against
 # the committed goldens, the CPU twin of the device arithmetic, gloo sharding — needs gcc/g++ only
 _NEEDS_HIP_LIB = {"test_abi", "test_gpu_parity", "test_host_state", "test_legacy_flavour", "test_no_gpu_behaviour",
-                  "test_ppm", "test_preview", "test_unpack"}
+                  "test_ppm", "test_preview", "test_shard", "test_unpack"}
 
 
 def pytest_configure(config):

@@ -1,0 +1,175 @@
+"""The sharded step behind the C ABI (include/rpf.h rpf_shard_*; rawphotoforge_amd/csrc/rpf_shard.cpp): the code RCCL
+drives on an 8-GPU node, exercised on ONE GPU — with pre-filled halos at the per-rank geometries of BASELINE
+configs[2] over 8 GPUs (6000 x 500 bands) and configs[3] (12000 x 1000 bands), and with a real RCCL exchange in which a
+rank is its own neighbour above and below (its first rows land in its top halo, its last rows in its bottom halo).
+All comparisons are bit-for-bit against the oracle's answer for the band."""
+import numpy as np
+import pytest
+
+import oracle as O
+import rawphotoforge_amd as R
+from rawphotoforge_amd import synthetic as syn
+from rawphotoforge_amd import tiles
+from tests import util
+
+gpu_only = pytest.mark.gpu
+
+
+def _exact(got, want):
+    d = util.ulp_diff(np.asarray(got, np.float32).reshape(want.shape), want)
+    assert d.max() == 0, f"{int((d > 0).sum())} of {d.size} values differ, max {int(d.max())} ulp"
+
+
+def _band_with_halos(frame, y0, rows):
+    """(rows + 4, W) int16 view of frame rows y0 - 2 .. y0 + rows + 1 (zero outside the frame: never read)."""
+    h, w = frame.shape
+    pad = np.zeros((rows + 4, w), np.uint16)
+    lo, hi = max(y0 - 2, 0), min(y0 + rows + 2, h)
+    pad[lo - (y0 - 2):hi - (y0 - 2)] = frame[lo:hi]
+    return pad
+
+
+@gpu_only
+@pytest.mark.parametrize("geom", [(6000, 4000, 8, 3, "D"), (6000, 4000, 8, 7, "S"), (12000, 8000, 8, 0, "D"),
+                                  (12000, 8000, 8, 4, "S"), (300, 231, 3, 1, "G"), (300, 231, 3, 2, "S")])
+def test_split_schedule_on_prefilled_halos_equals_oracle(gpu, geom):
+    """Interior launch on the caller's stream + ONE edge launch (first and last rows) on the library's side stream,
+    halos already in place: the per-rank geometry of the 8-GPU configurations, against the oracle's rows of the
+    whole frame (the oracle computes only the band: a whole 96-MP frame would take minutes)."""
+    torch = pytest.importorskip("torch")
+    w, h, world, rank, pname = geom
+    y0, rows = tiles.split_rows(h, world)[rank]
+    frame = util.bayer_uniform(h, w, seed=77)
+    rp = util.raw_params()
+    spec = syn.PARAM_SETS[pname]
+    want = O.develop(frame, rp, [util.oracle_params(spec)], y0=y0, rows=rows)
+    band = torch.from_numpy(_band_with_halos(frame, y0, rows).view(np.int16)).cuda()
+    out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+    sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), force_split=True)
+    assert sd.split
+    for _ in range(3):  # repeated steps: the gate / done events order the reuse of band and out
+        sd.step(band, out, R.OUT_RGBA_F32, exchange=False)
+    torch.cuda.synchronize()
+    _exact(out.cpu().numpy(), want)
+    out2 = torch.zeros_like(out)   # and equal to the single launch over the same band
+    tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec)).step(band, out2, exchange=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+@gpu_only
+def test_split_schedule_with_user_masks_and_odd_rows(gpu):
+    """Band-sized user masks (the edge launch reads the first and last rows of the mask-bit plane, the interior
+    launch the rows in between) on bands with an odd number of rows and an odd first row."""
+    torch = pytest.importorskip("torch")
+    h, w = 207, 140
+    cfa = util.bayer_uniform(h, w, seed=5)
+    rp = util.raw_params()
+    rng = np.random.default_rng(21)
+    main, a, b = util.params_D(), util.params_S(), util.params_G()
+    ma = np.where(rng.random((h, w)) > 0.5, 1.0, -1.0).astype(np.float32)
+    mb = np.full((h, w), -1.0, np.float32)
+    mb[4:150, 30:120] = 1.0
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(ma), O.binarize_mask(mb)])
+    want = O.develop(cfa, rp, [main, a, b], masks=masks)
+    for y0, rows in ((0, 91), (91, 116), (33, 47)):
+        def configure(e, y0=y0, rows=rows):
+            e.add_mask("a", ma[y0:y0 + rows])
+            e.add_mask("b", mb[y0:y0 + rows].reshape(-1))
+            util.configure_editor(e, main)
+            util.configure_editor(e, a, "a", main=False)
+            util.configure_editor(e, b, "b", main=False)
+        band = torch.from_numpy(_band_with_halos(cfa, y0, rows).view(np.int16)).cuda()
+        out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+        sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), configure, force_split=True)
+        assert sd.split and sd.ed.num_masks == 3
+        sd.step(band, out, exchange=False)
+        torch.cuda.synchronize()
+        _exact(out.cpu().numpy(), want[y0:y0 + rows])
+
+
+@gpu_only
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rccl_exchange_with_itself_as_neighbour(gpu, overlap):
+    """ncclCommInitRank / ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd as rpf_shard_develop issues them, on a
+    one-rank communicator whose rank is its own neighbour above and below.  The band is the middle of a frame whose
+    rows above / below it are the band's own first / last two rows: the exchanged halos must reproduce the oracle's
+    answer for that frame, with garbage in the halo rows beforehand."""
+    torch = pytest.importorskip("torch")
+    w, rows = 520, 96
+    band_rows = util.bayer_uniform(rows, w, seed=9)
+    frame = np.concatenate([band_rows[:2], band_rows, band_rows[-2:]])   # y0 = 2: the halos ARE those copies
+    h = frame.shape[0]
+    rp = util.raw_params()
+    spec = syn.PARAM_SETS["S"]
+    want = O.develop(frame, rp, [util.oracle_params(spec)], y0=2, rows=rows)
+    pad = np.full((rows + 4, w), 12345, np.uint16)
+    pad[2:-2] = band_rows
+    band = torch.from_numpy(pad.view(np.int16)).cuda()
+    out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+    shard = R.Shard(gpu, None, 0, 1)
+    shard.set_neighbours(0, 0)
+    info = shard.info()
+    assert (info["rank"], info["world"], info["up"], info["down"]) == (0, 1, 0, 0) and ":" in info["pci_bus_id"]
+    sd = tiles.ShardedDeveloper(gpu, w, h, 2, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), shard=shard,
+                                overlap=overlap)
+    assert sd.split == overlap
+    for _ in range(3):
+        sd.step(band, out)
+    torch.cuda.synchronize()
+    got_band = band.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got_band[:2], band_rows[:2]) and np.array_equal(got_band[-2:], band_rows[-2:])
+    _exact(out.cpu().numpy(), want)
+
+
+@gpu_only
+def test_packed_band_through_the_sharded_step(gpu):
+    """12-bit LSB-first packed rows (halo rows packed too) through interior + edge launches."""
+    torch = pytest.importorskip("torch")
+    h, w, y0, rows = 160, 256, 40, 80
+    frame = util.bayer_uniform(h, w, seed=3) & 0x0FFF
+    rp = O.RawParams(black=(256,) * 4, white=4095.0)
+    spec = syn.PARAM_SETS["S"]
+    want = O.develop(frame, rp, [util.oracle_params(spec)], y0=y0, rows=rows)
+    packed = O.pack_bayer(_band_with_halos(frame, y0, rows), 12, order=O.PACK_LSB_FIRST)
+    pb = torch.from_numpy(np.ascontiguousarray(packed)).cuda()
+    out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+    sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), force_split=True,
+                                packed=(12, packed.shape[1], R.PACK_LSB_FIRST))
+    sd.step(pb, out, exchange=False)
+    torch.cuda.synchronize()
+    _exact(out.cpu().numpy(), want)
+
+
+@gpu_only
+def test_shard_argument_errors(gpu):
+    torch = pytest.importorskip("torch")
+    with pytest.raises(R.InvalidArgument):
+        R.Shard(gpu, None, 0, 2)           # more than one rank needs the id
+    with pytest.raises(R.InvalidArgument):
+        R.Shard(gpu, None, 3, 2)
+    sh = R.Shard(gpu, None, 0, 1)
+    with pytest.raises(R.InvalidArgument):
+        sh.set_neighbours(1, -1)           # outside the communicator
+    ed = R.PhotoEditor.for_tile(gpu, 64, 64, 0, 64)
+    ed.set_lens_distortion_correction(10)
+    band = torch.zeros((68, 64), dtype=torch.int16, device="cuda")
+    out = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(R.InvalidArgument):  # a whole-frame resample does not shard
+        sh.develop(ed, band.data_ptr(), util.to_raw(util.raw_params()), out.data_ptr())
+
+
+def test_shard_entry_points_refuse_null_handles(hip_lib):
+    """Device-free: the sharding entry points exist, reject null handles with RPF_ERR_INVALID_ARGUMENT and leave a
+    message behind (a processor cannot exist without a GPU, so nothing behind them can compute here)."""
+    import ctypes as C
+    from rawphotoforge_amd import _native as N
+    lib = N.lib()
+    h = C.c_void_p()
+    assert lib.rpf_shard_create(None, None, 0, 1, C.byref(h)) == N.ERR_INVALID_ARGUMENT and not h.value
+    assert N.last_error()
+    assert lib.rpf_shard_set_neighbours(None, 0, 0) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_exchange(None, None, 0, 0, None) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_develop(None, None, None, 0, 0, 0, None, None, 0, None, 0) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_info(None, None, None, None, None, None, 0) == N.ERR_INVALID_ARGUMENT
+    lib.rpf_shard_destroy(None)   # a no-op, like free(NULL)
