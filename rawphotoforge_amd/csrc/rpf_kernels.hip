@@ -1135,8 +1135,12 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     // for the 1024-thread kernels that keep the brightness curve in LDS (4096 waves, 16-row items before), no change
     // for the 256-thread kernels (variant 14 forces it there, variant 15 switches it off everywhere; A/B).
     bool whole_rounds = false;
+    // A launch too small for two rounds of 32-row items (a row band of a frame sharded over several GPUs: 6000 x 500 is
+    // 5734 eight-row items for 5120 waves, i.e. one round plus a tail, every item paying its 4-row window start-up) takes
+    // whole rounds with any workgroup size: 29.6 -> see profiles/r03_experiments.md.
+    const bool small_launch = MODE != MODE_DEMOSAIC && a.seg_pairs != big;
     if (!seg_pairs && MODE != MODE_DEMOSAIC && cfg.variant != 15 && cfg.variant != 8 && cfg.variant != 9 &&
-        (LDS_LUT || cfg.variant == 14)) {
+        (LDS_LUT || cfg.variant == 14 || small_launch)) {
         for (uint32_t r = 1; r <= 8 && !whole_rounds; ++r) {
             const uint32_t segs = r * cap_waves / a.strips;
             if (segs == 0) continue;

@@ -1,25 +1,12 @@
 """Device functions of rpf_math.h without a bit-identical host twin (they start from gfx950's approximate
 v_rsq_f32), checked ON THE GPU over whole ranges of binary32 inputs (run on the GPU box: -m gpu)."""
 import ctypes as C
-import os
-import subprocess
 
 import pytest
 
+from tests.util import build_checker  # lives in a module without a pytest import: __graft_entry__.build() uses it too
+
 pytestmark = pytest.mark.gpu
-
-HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "gpu_math", "gpu_math_check.hip")
-LIB = os.path.join(HERE, "gpu_math", "librpf_gpu_math_check.so")
-HDR = os.path.join(HERE, "..", "rawphotoforge_amd", "csrc", "rpf_math.h")
-
-
-def build_checker(force=False) -> str:
-    """hipcc cross-compiles the checker without a GPU (also called by __graft_entry__.build)."""
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--offload-arch=gfx950", "-O3",
-                        "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", SRC, "-o", LIB], check=True)
-    return LIB
 
 
 @pytest.fixture(scope="module")

@@ -659,7 +659,7 @@ def test_bench_prints_one_contract_line(gpu, capsys, monkeypatch, extra):
     import importlib
     import json
     import sys
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "6", "--warmup", "2", "--preheat", "4", "--cpu-seconds", "0.5"] + extra)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "6", "--warmup", "2", "--preheat", "4", "--cpu-seconds", "0.5", "--secondary-steps", "8"] + extra)
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     bench = importlib.import_module("bench")
@@ -669,11 +669,25 @@ def test_bench_prints_one_contract_line(gpu, capsys, monkeypatch, extra):
     r = json.loads(lines[0])
     base = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")))
     assert r["metric"] == base["metric"] and r["unit"] == "MP/s" and r["n_gpus"] == 1 and r["steps"] == 6 and r["warmup"] == 2
-    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["data"] == "synthetic"
+    batch = "batch" in extra
+    assert r["higher_is_better"] is True and r["vs_baseline"] is None and r["data"] == "synthetic"
+    # ONE frame however many GPUs (north_star) = strong scaling; the batch of different frames is replicas = weak
+    assert r["scaling"] == ("weak" if batch else "strong") and r["config"]["mode"] == ("replicas" if batch else "strong")
+    assert r["config"]["input_resident"] == ("hbm" if batch else "infinity_cache")
+    assert r["config"]["world_size"] == 1 and len(r["config"]["ranks"]) == 1 and r["config"]["ranks"][0]["band"] == [0, 4000]
     assert r["value"] > 0 and abs(r["ms_per_step"] - 24.0 / r["value"] * 1e3) < 1e-2 * r["ms_per_step"]
     assert "workload" in r["config"] and "model" not in r["config"]
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "traffic" in rf
+    if rf["traffic"] is not None:   # replayed from the committed PMC pass of the same command, and labelled so
+        assert rf["traffic_measured_in_this_run"] is False
+    if not extra:   # the headline line also carries the kernel a user's edits dispatch and input that comes from HBM
+        sec = r["secondary"]
+        assert "pristine" in r["config"]["workload"] and "Infinity Cache" in r["config"]["workload"]
+        for e in (sec["edit_set_S"], sec["fresh_input"]["with_prefetch"], sec["fresh_input"]["without_prefetch"]):
+            assert e["kernel_ms_avg"] > 0 and 0 < e["frac"] < 1 and abs(e["frac"] - e["achieved_GB/s"] / 8000.0) < 1e-3
+    else:
+        assert "secondary" not in r
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "MP/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]

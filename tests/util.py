@@ -27,6 +27,21 @@ def build_twin(force=False) -> str:
     return TWIN_LIB
 
 
+# Device functions checked ON THE GPU over whole binary32 ranges (tests/test_gpu_math.py): the checker's build lives here,
+# in a module with no pytest import, because __graft_entry__.build() compiles it too (hipcc cross-compiles without a GPU).
+CHECKER_SRC = os.path.join(ROOT, "tests", "gpu_math", "gpu_math_check.hip")
+CHECKER_LIB = os.path.join(ROOT, "tests", "gpu_math", "librpf_gpu_math_check.so")
+CHECKER_HDR = os.path.join(ROOT, "rawphotoforge_amd", "csrc", "rpf_math.h")
+
+
+def build_checker(force=False) -> str:
+    if force or not os.path.exists(CHECKER_LIB) or os.path.getmtime(CHECKER_LIB) < max(os.path.getmtime(CHECKER_SRC),
+                                                                                      os.path.getmtime(CHECKER_HDR)):
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--offload-arch=gfx950", "-O3",
+                        "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", CHECKER_SRC, "-o", CHECKER_LIB], check=True)
+    return CHECKER_LIB
+
+
 _twin = None
 
 
