@@ -55,7 +55,7 @@ def main():
                     help="N > 1: weak scaling, a 6000x4000 band per rank of a 6000 x (4000 N) frame (the default is strong "
                          "scaling of ONE 6000x4000 frame, which is what BASELINE.json's north_star states)")
     ap.add_argument("--frames", type=int, default=8, help="--workload batch: frames in each GPU's pool (8 x 8 GPUs = 64)")
-    ap.add_argument("--params", default="D", choices=["D", "S", "G", "V", "T"])
+    ap.add_argument("--params", default="D", choices=["D", "S", "G", "V", "T", "B", "C"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--out", default="rgba", choices=["rgba", "rgb", "u8"], help="output layout of the fused kernel")

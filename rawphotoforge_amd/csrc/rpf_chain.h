@@ -67,18 +67,30 @@ RPF_HD float cfa_normalise(uint32_t raw, int cell, const RawParamsDev& rp)
     return n * rp.scale[cell];
 }
 
+// The formulas as DESIGN.md §3 states them, e.g. cross = ((4 c + 2 (s1 + e1)) - (v2 + h2)) / 8, one binary32 rounding
+// per operation.  Every factor that is a power of two scales exactly (no operand here is subnormal: samples are 0 or
+// >= 1e-5 and the sums cancel to 0 or to a multiple of their ulp), and RN(2^k x) = 2^k RN(x), so the division by 8 can
+// be carried into the terms and each "power of two times a term, plus a term" becomes ONE fma whose product is exact:
+// the same roundings in the same order with 19 instead of 29 instructions for the four values of a pixel pair.
 RPF_HD float mhc_cross(float c, float s1, float e1, float v2, float h2)
 {
-    return ((4.0f * c + 2.0f * (s1 + e1)) - (v2 + h2)) * 0.125f;
+    // ((4 c + 2 t) - u) / 8  ==  RN(RN(0.25 t + 0.5 c) - 0.125 u)
+    const float x = __builtin_fmaf(0.25f, s1 + e1, 0.5f * c);
+    return __builtin_fmaf(-0.125f, v2 + h2, x);
 }
 RPF_HD float mhc_diag(float c, float d, float v2, float h2)
 {
-    return ((6.0f * c + 2.0f * d) - 1.5f * (v2 + h2)) * 0.125f;
+    // ((6 c + 2 d) - 1.5 u) / 8  ==  RN(RN(0.25 d + RN(0.75 c)) - RN(0.1875 u))
+    return __builtin_fmaf(0.25f, d, 0.75f * c) - 0.1875f * (v2 + h2);
 }
 RPF_HD float mhc_axis(float c, float along, float d, float same2, float other2)
 {
     // horiz: along = e1, same2 = h2, other2 = v2;  vert: along = s1, same2 = v2, other2 = h2
-    return ((((5.0f * c + 4.0f * along) - d) - same2) + 0.5f * other2) * 0.125f;
+    // ((((5 c + 4 along) - d) - same2) + 0.5 other2) / 8, the division carried through every term
+    float x = __builtin_fmaf(0.5f, along, 0.625f * c);
+    x = __builtin_fmaf(-0.125f, d, x);
+    x = __builtin_fmaf(-0.125f, same2, x);
+    return __builtin_fmaf(0.0625f, other2, x);
 }
 
 RPF_HD void cam_to_linear(const float* m, float R, float G, float B, float& r, float& g, float& b)
@@ -293,6 +305,15 @@ RPF_HD const MaskParams& mask_params_user(const MaskParams* mp, uint32_t m) { re
 // LdsMaskParams): read through the kernel-argument pointer inside the per-mask loop, every field is a scalar load of
 // its own with its own wait, per mask per pixel.
 
+// Constants the kernels want in vector registers: the operand of an operation that carries the clamp modifier (VOP3:
+// no literal on gfx9, so the compiler parks it in a scalar register, and an SGPR operand halves the f32 rate), and
+// "main"'s constant saturation / lightness gains.  Any Tabs type without overloads of its own (the host twin's
+// MathTables) gets the plain values; rpf_kernels.hip overloads them for LdsTabs.
+template <class Tabs> RPF_HD float chain_k_gamma_lin(const Tabs&) { return RPF_F(12.92); }
+template <class Tabs> RPF_HD float chain_k_gamma_off(const Tabs&) { return RPF_F(0.055); }
+template <class Tabs> RPF_HD float chain_main_sat(const Tabs&, const MaskParams& P) { return P.sat_gain; }
+template <class Tabs> RPF_HD float chain_main_light(const Tabs&, const MaskParams& P) { return P.light_gain; }
+
 // STATIC_FLAGS (>= 0): "main"'s flag word, known at compile time (the caller's promise that mp[0].flags equals it).
 template <int N, bool HUE_DIRECT = false, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
 RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],
@@ -356,7 +377,8 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         for (int n = 0; n < N; ++n) {
             const uint32_t hu = main_mask ? hu0[n] : (uint32_t)(h[n] * 65535.0f);
             uint32_t nh = hu;
-            float sat_gain = P.sat_gain, light_gain = P.light_gain;
+            float sat_gain = main_mask ? chain_main_sat(T, P) : P.sat_gain;
+            float light_gain = main_mask ? chain_main_light(T, P) : P.light_gain;
             if (!trivial) luts.hsl(m, hu, P, nh, sat_gain, light_gain);
             const bool on = main_mask ? true : (bool)((active[n] >> m) & 1u);
             hue_k[n] = on ? nh : hue_k[n];
@@ -387,8 +409,8 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
             const float c = lin[k];
             // clamp(select(a, b)) == select(clamp(a), clamp(b)); written this way each clamp is the free output
             // modifier of the multiplication / addition in front of it instead of a v_max of its own
-            const float hi = clamp01(RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - RPF_F(0.055));  // unused when c <= thr
-            const float lo = clamp01(c * RPF_F(12.92));
+            const float hi = clamp01(RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - chain_k_gamma_off(T));  // unused when c <= thr
+            const float lo = clamp01(c * chain_k_gamma_lin(T));
             out[k] = c <= RPF_F(0.0031308) ? lo : hi;
         }
         r[n] = out[0]; g[n] = out[1]; b[n] = out[2];

@@ -49,9 +49,20 @@ constexpr bool mode_single(int mode) { return mode == MODE_DEVELOP_1 || mode == 
 struct LdsTabs {
     LdsPowTable cbrt, gamma;
     const SinCosTable& sc;
-    __device__ __forceinline__ LdsTabs(uint32_t base, const MathTables* T)
-        : cbrt{base + (uint32_t)offsetof(MathTables, cbrt)}, gamma{base + (uint32_t)offsetof(MathTables, gamma)}, sc(T->sc) {}
+    // launch-long constants in vector registers (rpf_chain.h chain_k_*, rpf_math.h pow_c3)
+    float k_gamma_lin, k_gamma_off, main_sat, main_light;
+    __device__ __forceinline__ LdsTabs(uint32_t base, const MathTables* T, const MaskParams& main)
+        : cbrt{base + (uint32_t)offsetof(MathTables, cbrt), PowCoef<POW_CBRT>::c3},
+          gamma{base + (uint32_t)offsetof(MathTables, gamma), PowCoef<POW_GAMMA>::c3}, sc(T->sc),
+          k_gamma_lin(12.92f), k_gamma_off(0.055f), main_sat(main.sat_gain), main_light(main.light_gain)
+    {
+        asm volatile("" : "+v"(cbrt.c3), "+v"(gamma.c3), "+v"(k_gamma_lin), "+v"(k_gamma_off), "+v"(main_sat), "+v"(main_light));
+    }
 };
+__device__ __forceinline__ float chain_k_gamma_lin(const LdsTabs& T) { return T.k_gamma_lin; }
+__device__ __forceinline__ float chain_k_gamma_off(const LdsTabs& T) { return T.k_gamma_off; }
+__device__ __forceinline__ float chain_main_sat(const LdsTabs& T, const MaskParams&) { return T.main_sat; }
+__device__ __forceinline__ float chain_main_light(const LdsTabs& T, const MaskParams&) { return T.main_light; }
 // Mask parameters as the multi-mask kernels read them: "main" through the kernel-argument segment (loaded once, scalar
 // registers), a user mask's 48 bytes from a copy in LDS at byte address `lds_base` with three 16-byte reads per mask per
 // step — wave-uniform values in vector registers, so the tone arithmetic also runs at the full f32 rate (an SGPR operand
@@ -231,6 +242,35 @@ __device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T
     }
 }
 
+// The edit chain on a pixel pair in the depth of specialisation MODE names (see the enum above).
+template <int MODE, class Luts>
+__device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (&b)[2], const uint32_t (&active)[2],
+                                          const DeviceEdit& ed, const Luts& luts, const LdsTabs& T, uint32_t lds_mp)
+{
+    if (MODE == MODE_DEVELOP_1P) {
+        edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, ed.mp, 1u, luts, T);
+    } else if (MODE == MODE_DEVELOP_1H) {
+        edit_chain<2, true>(r, gg, b, active, ed.mp, 1u, luts, T);
+    } else if (MODE == MODE_DEVELOP_1) {
+        edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
+    } else if (MODE == MODE_DEVELOP_SEQ) {
+        for (int k = 0; k < 2; ++k) {
+            float r1[1] = {r[k]}, g1[1] = {gg[k]}, b1[1] = {b[k]};
+            const uint32_t a1[1] = {active[k]};
+            edit_chain<1>(r1, g1, b1, a1, ed.mp, ed.num_masks, luts, T);
+            r[k] = r1[0]; gg[k] = g1[0]; b[k] = b1[0];
+        }
+    } else if (MODE == MODE_DEVELOP_MPH) {
+        edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
+    } else if (MODE == MODE_DEVELOP_MP) {
+        edit_chain<2, false, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
+    } else if (lds_mp != 0xffffffffu) {
+        edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
+    } else {
+        edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
+    }
+}
+
 // The vertical pixel pair at one column: demosaic both sites (one is R/B, the other G), camera matrix,
 // then — MODE_DEVELOP — vignette and the edit chain on the pair in lockstep, and the two stores.
 // c/s1/e1/d/v2/h2 [0] = top pixel, [1] = bottom pixel.  cx = RGGB cell column of this lane, cy_top of the top row.
@@ -283,28 +323,7 @@ __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s
         uint32_t active[2] = {1u, 1u};
         if (!mode_single(MODE) && ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(ed, pix[k], (size_t)rows * W);
-        if (MODE == MODE_DEVELOP_1P) {
-            edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, ed.mp, 1u, luts, T);
-        } else if (MODE == MODE_DEVELOP_1H) {
-            edit_chain<2, true>(r, gg, b, active, ed.mp, 1u, luts, T);
-        } else if (MODE == MODE_DEVELOP_1) {
-            edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
-        } else if (MODE == MODE_DEVELOP_SEQ) {
-            for (int k = 0; k < 2; ++k) {
-                float r1[1] = {r[k]}, g1[1] = {gg[k]}, b1[1] = {b[k]};
-                const uint32_t a1[1] = {active[k]};
-                edit_chain<1>(r1, g1, b1, a1, ed.mp, ed.num_masks, luts, T);
-                r[k] = r1[0]; gg[k] = g1[0]; b[k] = b1[0];
-            }
-        } else if (MODE == MODE_DEVELOP_MPH) {
-            edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
-        } else if (MODE == MODE_DEVELOP_MP) {
-            edit_chain<2, false, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
-        } else if (lds_mp != 0xffffffffu) {
-            edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
-        } else {
-            edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
-        }
+        run_chain<MODE>(r, gg, b, active, ed, luts, T, lds_mp);
     }
     // rows past a ragged band: a wave-uniform test; columns past a ragged strip: the row descriptor's range check
     for (int k = 0; k < 2; ++k)
@@ -342,6 +361,9 @@ struct StreamArgs {
     // PART_EDGES launches (row-tile sharding): segments from skip_from on lie skip_pairs row pairs further down, so one
     // launch covers the band's first and last rows and nothing in between (skip_from = ~0: no gap)
     uint32_t skip_from, skip_pairs;
+    // k_hp only: band rows [dead_lo, dead_hi) are computed where a segment reaches them but NOT stored (PART_EDGES on a
+    // band whose first row is not an R row: its steps straddle the part's boundaries); empty by default
+    uint32_t dead_lo, dead_hi;
 };
 
 // One CFA row of a strip as the wavefront sees it: v = this lane's sample; p1 / p2 = the W+E sums at
@@ -382,7 +404,7 @@ void k_stream(const StreamArgs a)
         __syncthreads();  // the only barrier of the kernel
     }
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
-    const LdsTabs tabs(0u, T);
+    const LdsTabs tabs(0u, T, a.ed.mp[0]);
     // the u16 band as one buffer: (rows + 4) rows of W samples (run_stream checks that it is shorter than 4 GiB)
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
@@ -546,6 +568,243 @@ void k_stream(const StreamArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// k_hp — horizontal-pair front end (round 3; the shipped fused kernel for u16 input)
+//
+// k_stream gives a lane ONE column and a vertical pixel pair, so which of the two pixels is the R/B site alternates from
+// lane to lane and every step pays 22 v_cndmask (half-rate on gfx950) to sort the pair into roles and back, plus six DPP
+// moves per row.  Here a wavefront owns a 128-column strip and lane l holds the two NEIGHBOURING columns 2l, 2l + 1 of it;
+// the strip starts on an R column (x0 = 128 strip - xo) and a step on an R row (band rows 2p - bp, 2p - bp + 1), so the
+// roles are the same in every lane and known at compile time: row 0 of a step is (R site, G), row 1 is (G, B site).
+// No select anywhere in the front end; the horizontal taps of BOTH columns come from four DPP moves per row (the lane's
+// own other column is a neighbour already); and the pair that goes through the edit chain in lockstep is the horizontal
+// one.  What a lane then holds — pixels 2l and 2l + 1 of a row — would make every store instruction write every other
+// 16 bytes of a line, which nontemporal stores take at a third of their rate (tools/store_probe.hip: 1.9 instead of
+// 5.5 TB/s); one v_permlane32_swap per channel moves the second pixels of lanes 0..31 into lanes 32..63 of the first
+// register (and vice versa), after which each of the two stores of a row covers one whole KiB (lanes 0..31 its even
+// pixels, lanes 32..63 its odd ones: 5.4 TB/s in the same probe).  Same arithmetic, same bits as k_stream.
+// The price: two columns' rolling windows in registers (about 110 VGPRs, four waves per SIMD instead of five).
+// ---------------------------------------------------------------------------
+constexpr int HP_STRIP_W = 128;
+
+struct HpRow { float va, vb, p1a, p1b, p2a, p2b; };
+
+// One CFA row of a strip, normalised: a / b = this lane's columns 2l, 2l + 1; ha / hb = the lane pair beyond the strip
+// (lane 0: columns x0 - 2, x0 - 1; lane 63: x0 + 128, x0 + 129; other lanes: don't care).  p1 = (x-1) + (x+1),
+// p2 = (x-2) + (x+2), left operand first as in row_taps.
+__device__ __forceinline__ HpRow hp_row_taps(float a, float b, float ha, float hb)
+{
+    const float a_l = from_left(a, ha);   // a of the lane to the left: x-2 of a
+    const float b_l = from_left(b, hb);   // b of the lane to the left: x-1 of a, x-2 of b
+    const float a_r = from_right(a, ha);  // a of the lane to the right: x+2 of a, x+1 of b
+    const float b_r = from_right(b, hb);  // x+2 of b
+    HpRow t;
+    t.va = a; t.vb = b;
+    t.p1a = b_l + b;
+    t.p1b = a + a_r;
+    t.p2a = a_l + a_r;
+    t.p2b = b_l + b_r;
+    return t;
+}
+
+// The two pixels (columns 2l, 2l + 1 of the strip) of output row `row` through vignette, edit chain and the stores.
+// colF: the column whose pixel this lane stores from the first register after the half-wave swap (second: + 64).
+template <int MODE, bool LDS_LUT, int OUTFMT, bool VIGN>
+__device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (&b)[2], int row, const int (&col)[2],
+                                          int colF, const TileGeom& g, const DeviceEdit& ed, const DevLuts<LDS_LUT>& luts,
+                                          const LdsTabs& T, void* out, const float (&vcx2)[2], float vcy2, uint32_t lds_mp,
+                                          uint32_t dead_lo, uint32_t dead_hi)
+{
+    const int W = (int)g.width, rows = (int)g.rows;
+    // wave-uniform: the virtual rows above / below a band, and the rows a PART_EDGES launch leaves to the interior's
+    const bool row_live = row >= 0 && row < rows && !((uint32_t)row >= dead_lo && (uint32_t)row < dead_hi);
+    if (VIGN) {  // wgsl:166-178, global coordinates
+        for (int k = 0; k < 2; ++k) {
+            const float gain = vignette_from_axes(ed.vign_strength, vcx2[k], vcy2);
+            r[k] *= gain; gg[k] *= gain; b[k] *= gain;
+        }
+    }
+    uint32_t active[2] = {1u, 1u};
+    if (!mode_single(MODE) && ed.num_masks > 1)
+        for (int k = 0; k < 2; ++k)  // col[] is clamped into the frame: dead lanes read a valid entry
+            active[k] = active_masks(ed, row_live ? (size_t)row * W + col[k] : 0, (size_t)rows * W);
+    run_chain<MODE>(r, gg, b, active, ed, luts, T, lds_mp);
+    // A row that is not stored gets an EMPTY descriptor (num_records 0: the hardware drops the stores) instead of a
+    // branch around them: behind a branch the compiler also sinks half of the chain, and the join then needs
+    // s_waitcnt vmcnt(0) — a drain of the row's own stores — because the chain's gathers are still in flight on the
+    // path that skipped their uses.  (Such rows are the one virtual row above / below a band: their work is noise.)
+    constexpr uint32_t BPP = out_bpp<OUTFMT>();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(out) + (size_t)(row_live ? row : 0) * (size_t)W * BPP, 0,
+        row_live ? (int)((uint32_t)W * BPP) : 0, RPF_BUFFER_RSRC_FLAGS);
+    // v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second
+    const auto sr = __builtin_amdgcn_permlane32_swap(f2bits(r[0]), f2bits(r[1]), false, false);
+    const auto sg = __builtin_amdgcn_permlane32_swap(f2bits(gg[0]), f2bits(gg[1]), false, false);
+    const auto sb = __builtin_amdgcn_permlane32_swap(f2bits(b[0]), f2bits(b[1]), false, false);
+    // a column left of the frame (x0 = -1 for CFA layouts that start on a G column) or right of it wraps to / lies at an
+    // offset beyond the row descriptor's num_records: dropped by the hardware's range check
+    const uint32_t offF = (uint32_t)colF * BPP;
+    store_px_buf<OUTFMT>(rs, offF, bits2f(sr[0]), bits2f(sg[0]), bits2f(sb[0]));
+    store_px_buf<OUTFMT>(rs, offF + 64u * BPP, bits2f(sr[1]), bits2f(sg[1]), bits2f(sb[1]));
+}
+
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool VIGN = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1)))
+void k_hp(const StreamArgs a)
+{
+    static_assert(MODE != MODE_DEMOSAIC, "the demosaic-only kernel is store-bound: k_stream");
+    extern __shared__ __align__(16) unsigned char smem[];
+    MathTables* T = reinterpret_cast<MathTables*>(smem);
+    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
+    const int tid = threadIdx.x;
+    constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
+    constexpr bool MULTI = mode_multi(MODE);
+    assert_lds_base(smem);
+    stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+    if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
+    __syncthreads();  // the only barrier of the kernel
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
+    const LdsTabs tabs(0u, T, a.ed.mp[0]);
+    const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
+
+    const int lane = tid & 63;
+    const int W = (int)a.g.width, H = (int)a.g.height;
+    const int y0 = (int)a.g.y0, rows = (int)a.g.rows;
+    const int bp = (y0 + a.raw.yo) & 1;  // step p covers band rows 2p - bp (RGGB cell row 0) and 2p - bp + 1
+    const int total_pairs = (rows + bp + 1) / 2;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + (tid >> 6));
+    const uint32_t nwaves = gridDim.x * (NT / 64);
+
+    // Normalisation: n = med3(f32(raw) - black, 0, range) * scale per RGGB cell (cx + 2 cy).  Black and scale feed
+    // full-rate f32 operations and therefore live in vector registers (an SGPR operand halves the rate); the range is
+    // an operand of v_med3_f32, which is half-rate with any operand.
+    float blk[4], scl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        blk[i] = a.raw.black[i]; scl[i] = a.raw.scale[i];
+        asm volatile("" : "+v"(blk[i]), "+v"(scl[i]));
+    }
+    float camv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        camv[i] = a.raw.cam[i];
+        asm volatile("" : "+v"(camv[i]));
+    }
+    auto norm = [&](uint32_t raw, int cell) {
+        return __builtin_amdgcn_fmed3f((float)raw - blk[cell], 0.0f, a.raw.range[cell]) * scl[cell];
+    };
+    // pixel of the first 64 of a strip that this lane stores after the half-wave swap (hp_finish)
+    const int pxF = lane < 32 ? 2 * lane : 2 * (lane - 32) + 1;
+
+    for (uint32_t vitem = wave; vitem < a.nvirt; vitem += nwaves) {
+        uint32_t item = vitem, sub = 0, sub_pairs = a.seg_pairs;
+        if (vitem >= a.tail_start) {
+            const uint32_t t = vitem - a.tail_start;
+            item = a.tail_start + t / a.seg_pairs;
+            sub = t - (item - a.tail_start) * a.seg_pairs;
+            sub_pairs = 1;
+        }
+        const uint32_t seg = item / a.strips, strip = item - seg * a.strips;
+        const int x0 = (int)strip * HP_STRIP_W - a.raw.xo;  // an R column (of the frame, or the virtual column -1)
+        const int pair0 = (int)(seg * a.seg_pairs + sub + (seg >= a.skip_from ? a.skip_pairs : 0u));
+        const int npairs = min((int)sub_pairs, total_pairs - pair0);
+        if (npairs <= 0) continue;
+        const int xa = x0 + 2 * lane;
+        auto column = [&](int x) {  // reflect-101 at the frame edge; columns far outside (a ragged strip): any valid one
+            int c = reflect101(x, W);
+            return c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+        };
+        const int col[2] = {column(xa), column(xa + 1)};
+        const int hxa = lane == 0 ? xa - 2 : (lane == 63 ? xa + 2 : xa);  // the lane pair beyond the strip
+        const uint32_t goffa = (uint32_t)col[0] * 2u, goffb = (uint32_t)col[1] * 2u;  // byte offsets inside a u16 row
+        const uint32_t hoffa = (uint32_t)column(hxa) * 2u, hoffb = (uint32_t)column(hxa + 1) * 2u;
+        // Row addressing as in k_stream: lane j holds the byte offset of window row j of this item (band rows
+        // 2 pair0 - bp - 2 + j: reflect-101 at the frame edge, clamped inside the band buffer — a clamped row only ever
+        // feeds the virtual row above / below the band, which is not stored).  An item spans 2 seg_pairs + 4 <= 64 rows.
+        const int rbase = 2 * pair0 - bp - 2;
+        uint32_t rowoff;
+        {
+            int gy = reflect101(y0 + rbase + lane, H);
+            int br = gy - (y0 - 2);
+            br = br < 0 ? 0 : (br > rows + 3 ? rows + 3 : br);
+            rowoff = (uint32_t)br * (uint32_t)W * 2u;
+        }
+        struct Raw4 { uint32_t a, b, ha, hb; };
+        auto load_row = [&](int j) {  // j = window row of the item, wave-uniform
+            const uint32_t ro = __builtin_amdgcn_readlane(rowoff, j);
+            Raw4 q;
+            q.a = __builtin_amdgcn_raw_buffer_load_b16(band_rsrc, goffa, ro, 0);
+            q.b = __builtin_amdgcn_raw_buffer_load_b16(band_rsrc, goffb, ro, 0);
+            q.ha = __builtin_amdgcn_raw_buffer_load_b16(band_rsrc, hoffa, ro, 0);
+            q.hb = __builtin_amdgcn_raw_buffer_load_b16(band_rsrc, hoffb, ro, 0);
+            return q;
+        };
+        // window position i <-> band row 2 pair - bp - 2 + i: RGGB cell row i & 1; a is cell column 0, b cell column 1
+        auto taps = [&](const Raw4& q, int odd) {
+            return hp_row_taps(norm(q.a, 2 * odd), norm(q.b, 2 * odd + 1), norm(q.ha, 2 * odd), norm(q.hb, 2 * odd + 1));
+        };
+        float vcx2[2] = {0.0f, 0.0f}, vcy2_lane = 0.0f;
+        if (VIGN) {  // squared coordinates of the two columns once per item; lane j: of the item's output row j
+            vcx2[0] = vignette_axis2(xa, (float)W);
+            vcx2[1] = vignette_axis2(xa + 1, (float)W);
+            vcy2_lane = vignette_axis2(y0 + rbase + 2 + lane, (float)H);
+        }
+
+        float w0a, w0b;
+        {
+            const Raw4 q0 = load_row(0);
+            w0a = norm(q0.a, 0); w0b = norm(q0.b, 1);
+        }
+        HpRow t1 = taps(load_row(1), 1), t2 = taps(load_row(2), 0), t3 = taps(load_row(3), 1);
+        Raw4 n4 = load_row(4), n5 = load_row(5);
+
+        for (int p = 0; p < npairs; ++p) {  // wave-uniform
+            const HpRow t4 = taps(n4, 0), t5 = taps(n5, 1);
+            if (p + 1 < npairs) {  // prefetch the next step's two rows
+                n4 = load_row(2 * p + 6);
+                n5 = load_row(2 * p + 7);
+            }
+            const int row = 2 * (pair0 + p) - bp;
+            float vcy2[2] = {0.0f, 0.0f};
+            if (VIGN) {
+                vcy2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p));
+                vcy2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p + 1));
+            }
+            float r[2], gg[2], b[2];
+            {   // row 0 of the step (window position 2): a = R site, b = G site on the R row
+                const float s1a = t1.va + t3.va, s1b = t1.vb + t3.vb;
+                const float da = t1.p1a + t3.p1a, db = t1.p1b + t3.p1b;
+                const float vva = w0a + t4.va, vvb = w0b + t4.vb;
+                const float cross = mhc_cross(t2.va, s1a, t2.p1a, vva, t2.p2a);
+                const float diag = mhc_diag(t2.va, da, vva, t2.p2a);
+                const float horiz = mhc_axis(t2.vb, t2.p1b, db, t2.p2b, vvb);
+                const float vert = mhc_axis(t2.vb, s1b, db, vvb, t2.p2b);
+                cam_to_linear(camv, t2.va, cross, diag, r[0], gg[0], b[0]);
+                cam_to_linear(camv, horiz, t2.vb, vert, r[1], gg[1], b[1]);
+                hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[0],
+                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi);
+            }
+            {   // row 1 (window position 3): a = G site on the B row, b = B site
+                const float s1a = t2.va + t4.va, s1b = t2.vb + t4.vb;
+                const float da = t2.p1a + t4.p1a, db = t2.p1b + t4.p1b;
+                const float vva = t1.va + t5.va, vvb = t1.vb + t5.vb;
+                const float vert = mhc_axis(t3.va, s1a, da, vva, t3.p2a);
+                const float horiz = mhc_axis(t3.va, t3.p1a, da, t3.p2a, vva);
+                const float cross = mhc_cross(t3.vb, s1b, t3.p1b, vvb, t3.p2b);
+                const float diag = mhc_diag(t3.vb, db, vvb, t3.p2b);
+                cam_to_linear(camv, vert, t3.va, horiz, r[0], gg[0], b[0]);
+                cam_to_linear(camv, diag, cross, t3.vb, r[1], gg[1], b[1]);
+                hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row + 1, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[1],
+                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi);
+            }
+            // slide the window down two rows
+            w0a = t2.va; w0b = t2.vb;
+            t1 = t3; t2 = t4; t3 = t5;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_tile — LDS-tile front end (variant 1): persistent workgroups walk 128 x TILE_H tiles; the
 // (TILE_H+4) x 132 normalised CFA neighbourhood is staged in LDS, lanes read their 6-row column and
 // take the horizontal taps by DPP (lanes 0/63 patch the two samples beyond the wavefront from LDS).
@@ -578,7 +837,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
         assert_lds_base(smem);
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     }
-    const LdsTabs tabs((uint32_t)((TILE_ELEMS * 4 + 15) & ~15), T);
+    const LdsTabs tabs((uint32_t)((TILE_ELEMS * 4 + 15) & ~15), T, a.ed.mp[0]);
     const int lx = tid & (TILE_W - 1);
     const int ly = 2 * (tid / TILE_W);
     const int lane = tid & 63;
@@ -665,7 +924,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
-    const LdsTabs tabs(0u, T);
+    const LdsTabs tabs(0u, T, a.ed.mp[0]);
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
     const uint32_t stride = gridDim.x * NT * 2;
@@ -1177,6 +1436,87 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     return hipGetLastError();
 }
 
+// k_hp's launcher: 128-column strips that start on an R column, steps that start on an R row (see the kernel).
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
+                         const DeviceEdit* ed, void* d_out, hipStream_t s)
+{
+    StreamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.skip_from = 0xffffffffu;
+    a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
+    a.ed = *ed;
+    const uint32_t bp = (g.y0 + (uint32_t)raw.yo) & 1u;
+    const uint32_t total_pairs = (g.rows + bp + 1) / 2;
+    a.strips = (g.width + (uint32_t)raw.xo + HP_STRIP_W - 1) / HP_STRIP_W;
+    constexpr uint32_t WPB = NT / 64;
+    const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
+                       (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
+    const bool vign = ed->vign_strength != 0.0f;
+    auto kernel = vign ? k_hp<NT, MODE, LDS_LUT, OUTFMT, true> : k_hp<NT, MODE, LDS_LUT, OUTFMT, false>;
+    hipError_t e = set_lds(kernel, lds);
+    if (e != hipSuccess) return e;
+    // persistent workgroups, as many as are resident: four 256-thread workgroups per CU (about 110 VGPRs: four waves per
+    // SIMD), one 1024-thread workgroup where the 128-KiB curve is staged in LDS
+    uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)(1024 / NT);
+    {
+        static std::atomic<int> resident[2];
+        int nb = resident[vign].load(std::memory_order_relaxed);
+        if (nb == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NT, lds) != hipSuccess || nb < 1) nb = 1;
+            resident[vign].store(nb, std::memory_order_relaxed);
+        }
+        if (per_cu > (uint32_t)nb) per_cu = (uint32_t)nb;
+    }
+    const uint32_t cap_waves = (uint32_t)cfg.num_cus * per_cu * WPB;
+    auto items_for = [&](uint32_t sp) { return a.strips * ((total_pairs + sp - 1) / sp); };
+    // Whole rounds (see run_stream): the fewest rounds R for which a strip cut into floor(R * waves / strips) equal
+    // segments gives items of 4..30 row pairs; 6000 x 4000 on 4096 waves is ONE round of 4089 items of 23 pairs.
+    a.seg_pairs = 4;
+    bool whole_rounds = false;
+    for (uint32_t r = 1; r <= 8 && !whole_rounds; ++r) {
+        const uint32_t segs = r * cap_waves / a.strips;
+        if (segs == 0) continue;
+        const uint32_t sp = (total_pairs + segs - 1) / segs;
+        if (sp >= 4 && sp <= 30) { a.seg_pairs = sp; whole_rounds = true; }
+    }
+    if (!whole_rounds && items_for(16) >= 2 * cap_waves) a.seg_pairs = 16;
+    a.nitems = items_for(a.seg_pairs);
+    if (cfg.part == PART_EDGES) {  // the band's first 8 rows and its last 7 or 8 (rpf_launch.h), whatever row the steps start on
+        const uint32_t tp0 = (g.rows + 1) / 2, ep = EDGE_PAIRS + bp;
+        if (tp0 < 2 * EDGE_PAIRS || total_pairs < 2 * ep) return hipErrorInvalidValue;
+        a.dead_lo = 2 * EDGE_PAIRS;
+        a.dead_hi = 2 * (tp0 - EDGE_PAIRS);
+        a.seg_pairs = ep;
+        a.nitems = a.strips * 2;
+        a.skip_from = 1;
+        a.skip_pairs = total_pairs - 2 * ep;
+        whole_rounds = true;
+    }
+    uint32_t grid = (a.nitems + WPB - 1) / WPB;
+    const uint32_t cap = (uint32_t)cfg.num_cus * per_cu;
+    if (grid > cap) grid = cap;
+    a.tail_start = a.nvirt = a.nitems;
+    if (!whole_rounds) {  // the last, incomplete round in single-pair sub-items (see StreamArgs)
+        const uint32_t nwaves = grid * WPB;
+        if (a.nitems > nwaves) {
+            a.tail_start = a.nitems / nwaves * nwaves;
+            a.nvirt = a.tail_start + (a.nitems - a.tail_start) * a.seg_pairs;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+// The fused kernel of a u16 band: k_hp, or the column-per-lane k_stream where a measurement variant asks for it.
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+static hipError_t run_fused(bool hp, const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
+                            const DeviceEdit* ed, void* d_out, hipStream_t s)
+{
+    return hp ? run_hp<NT, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s)
+              : run_stream<NT, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s);
+}
+
 template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
 static hipError_t run_tile(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                            const DeviceEdit* ed, void* d_out, int blocks_per_cu, hipStream_t s)
@@ -1225,22 +1565,25 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
                    : run_stream<512, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
     if (OUTFMT == OUT_RGBA_F32 && !lut && cfg.variant == 3)  // A/B: the pixel pair one after the other
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    // the shipped kernel is k_hp; the column-per-lane k_stream stays for A/B: variant 20, and the variants that are
+    // options of its launcher (6, 8, 9, 14, 15); 7, 10, 11, 12 choose the specialisation and apply to either
+    const bool hp = cfg.variant == 0 || cfg.variant == 7 || cfg.variant == 10 || cfg.variant == 11 || cfg.variant == 12;
     if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
         if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // variant 12 (A/B): run-time flags also for a pristine "main"
-            return run_stream<256, MODE_DEVELOP_1P, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+            return run_fused<256, MODE_DEVELOP_1P, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
         if ((ed.mp[0].flags & MF_HUE_IDENTITY) && cfg.variant != 11)  // variant 11 (A/B): sincos_hue also for an identity hue curve
-            return lut ? run_stream<1024, MODE_DEVELOP_1H, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
-                       : run_stream<256, MODE_DEVELOP_1H, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
-        return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
-                   : run_stream<256, MODE_DEVELOP_1, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+            return lut ? run_fused<1024, MODE_DEVELOP_1H, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
+                       : run_fused<256, MODE_DEVELOP_1H, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
+        return lut ? run_fused<1024, MODE_DEVELOP_1, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
+                   : run_fused<256, MODE_DEVELOP_1, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
     }
     if (!lut && ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12) {  // user masks over an untouched "main"
         if (all_hue_identity(ed) && cfg.variant != 11)
-            return run_stream<256, MODE_DEVELOP_MPH, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
-        return run_stream<256, MODE_DEVELOP_MP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+            return run_fused<256, MODE_DEVELOP_MPH, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
+        return run_fused<256, MODE_DEVELOP_MP, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
     }
-    return lut ? run_stream<1024, MODE_DEVELOP, true, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s)
-               : run_stream<256, MODE_DEVELOP, false, OUTFMT>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    return lut ? run_fused<1024, MODE_DEVELOP, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
+               : run_fused<256, MODE_DEVELOP, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
 }
 
 template <int OUTFMT, int PK>

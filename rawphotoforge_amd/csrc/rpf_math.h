@@ -138,6 +138,10 @@ RPF_HD void pow_table_read(const PowTable& T, uint32_t eoff, uint32_t joff, doub
 // `extern __shared__` symbol the compiler adds the (zero) base to every offset first: 12 extra VALU per pixel.
 struct LdsPowTable {
     uint32_t base;
+    // The polynomial's first step is fma(t, c4, c3): two constants, and a VOP3 instruction of gfx9 reads only one operand
+    // over the constant bus — taken from the instruction stream, c3 costs a v_mov_b64 per evaluation (seven per 128-pixel
+    // step).  The kernels therefore keep it in a vector register pair for the whole launch (rpf_kernels.hip LdsTabs).
+    double c3;
 };
 typedef const __attribute__((address_space(3))) double* lds_cdouble_ptr;
 typedef double lds_double2 __attribute__((ext_vector_type(2)));
@@ -155,6 +159,14 @@ __device__ __forceinline__ void pow_table_read(const LdsPowTable& T, uint32_t eo
 }
 #endif
 
+// where the degree-3 coefficient comes from: the instruction stream, or a register pair the table object holds
+template <int KIND>
+RPF_HD double pow_c3(const PowTable&) { return PowCoef<KIND>::c3; }
+#if defined(__HIPCC__)
+template <int KIND>
+__device__ __forceinline__ double pow_c3(const LdsPowTable& T) { return T.c3; }
+#endif
+
 template <int KIND, class TabT>
 RPF_HD double powc_d(float x, const TabT& T)  // the binary64 value before the single rounding
 {
@@ -167,7 +179,7 @@ RPF_HD double powc_d(float x, const TabT& T)  // the binary64 value before the s
     const double t = __builtin_fma(m, r, -1.0);
     using K = PowCoef<KIND>;
 #if RPF_POW_BITS >= 9
-    double p = __builtin_fma(t, K::c4, K::c3);  // c5 t^5 < 2^-55: dropped
+    double p = __builtin_fma(t, K::c4, pow_c3<KIND>(T));  // c5 t^5 < 2^-55: dropped
 #else
     double p = __builtin_fma(t, K::c5, K::c4);
     p = __builtin_fma(t, p, K::c3);

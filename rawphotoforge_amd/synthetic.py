@@ -57,6 +57,8 @@ PARAM_SETS = {
     # single-stage sets for cost attribution (bench.py --params V / T): the defaults plus one stage
     "V": dict(vignette=-30),
     "T": dict(exposure=0.5, contrast=20, shadow=30, highlight=-20, black=5, white=-5, wb_temperature=15, wb_tint=-10),
+    "B": dict(brightness=("points", [0, 16384, 49152, 65535], [0, 20000, 52000, 65535])),   # S's brightness curve alone
+    "C": dict(saturation=("const", 40000)),                                                  # S's saturation curve alone
 }
 
 

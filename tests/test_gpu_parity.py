@@ -60,7 +60,7 @@ def test_demosaic_saturated_and_below_black(gpu):
 GOLD = np.load(os.path.join(util.GOLDEN, "chain_golden.npz"))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 10, 11])   # every A/B variant of rpf_set_kernel_variant: same bits
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 20])   # every A/B variant of rpf_set_kernel_variant: same bits
 @pytest.mark.parametrize("pname", ["D", "S"])
 @pytest.mark.parametrize("tag", ["U", "N"])
 def test_develop_matches_committed_golden(gpu, tag, pname, variant):

@@ -57,3 +57,32 @@ def test_random_parameter_space():
     for _ in range(30):
         n_masks = int(rng.integers(1, 4))
         _check([util.random_params(rng) for _ in range(n_masks)], n=20_000, seed=int(rng.integers(1 << 30)))
+
+
+def test_demosaic_formulas_with_carried_powers_of_two_equal_the_specification():
+    """rpf_chain.h evaluates the four Malvar-He-Cutler values with the division by 8 carried into the terms and every
+    'power of two times a term, plus a term' as one fma (19 instead of 29 instructions per pixel pair).  DESIGN.md §3 /
+    orc_demosaic state them with one binary32 rounding per operation in source order: the two must agree bit for
+    bit — on normalised samples as the kernels see them (n * scale, clamped), on their sums, and on zeros."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    n = 2_000_000
+    f = np.float32
+    scale = f(2.0) / f(16383 - 512)
+    def samples(k):
+        return (rng.integers(0, 15872, size=(k, n)).astype(f) * scale)
+    v = samples(13)                       # the 13 taps of a 5x5 cross neighbourhood
+    v[:, :1000] = 0                       # black areas
+    v[:, 1000:2000] = v[0, 1000:2000]     # flat areas (exact cancellation)
+    c = v[0]
+    s1, e1, d = v[1] + v[2], v[3] + v[4], (v[5] + v[6]) + (v[7] + v[8])
+    v2, h2 = v[9] + v[10], v[11] + v[12]
+    want_cross = ((f(4) * c + f(2) * (s1 + e1)) - (v2 + h2)) * f(0.125)
+    want_diag = ((f(6) * c + f(2) * d) - f(1.5) * (v2 + h2)) * f(0.125)
+    want_h = ((((f(5) * c + f(4) * e1) - d) - h2) + f(0.5) * v2) * f(0.125)
+    want_v = ((((f(5) * c + f(4) * s1) - d) - v2) + f(0.5) * h2) * f(0.125)
+    outs = [np.empty(n, f) for _ in range(4)]
+    P = lambda a: np.ascontiguousarray(a, f).ctypes.data_as(C.POINTER(C.c_float))
+    util.twin().twin_mhc(C.c_size_t(n), P(c), P(s1), P(e1), P(d), P(v2), P(h2), *[o.ctypes.data_as(C.POINTER(C.c_float)) for o in outs])
+    for got, want, name in zip(outs, (want_cross, want_diag, want_h, want_v), ("cross", "diag", "horiz", "vert")):
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want, f).view(np.uint32)), name

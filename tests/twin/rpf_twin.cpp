@@ -192,6 +192,18 @@ void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint3
 }
 }
 
+// ---- the demosaic formulas as the kernels evaluate them (rpf_chain.h mhc_*: powers of two carried into fma) ---------
+extern "C" void twin_mhc(size_t n, const float* c, const float* s1, const float* e1, const float* d, const float* v2,
+                         const float* h2, float* cross, float* diag, float* horiz, float* vert)
+{
+    for (size_t i = 0; i < n; ++i) {
+        cross[i] = rpf::mhc_cross(c[i], s1[i], e1[i], v2[i], h2[i]);
+        diag[i] = rpf::mhc_diag(c[i], d[i], v2[i], h2[i]);
+        horiz[i] = rpf::mhc_axis(c[i], e1[i], d[i], h2[i], v2[i]);
+        vert[i] = rpf::mhc_axis(c[i], s1[i], d[i], v2[i], h2[i]);
+    }
+}
+
 // ---- host state machine under sanitizers (tools/sanitize_cpu.sh) ---------------------------------
 extern "C" {
 // the PPM header grammar of the C ABI (rpf_host.h), for the sanitizer run and the no-GPU tests

@@ -5,7 +5,7 @@
 set -u
 TAG=$1; ARGS=$2; shift 2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-P="python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 10 --preheat 60 --no-cpu-baseline $ARGS"
+P="python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 10 --preheat 60 --no-cpu-baseline --no-secondary $ARGS"
 i=0
 for pmc in "$@"; do
   i=$((i+1))

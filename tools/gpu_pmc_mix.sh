@@ -3,7 +3,7 @@
 set -u
 TAG=${1:-mix}; PSET=${2:-D}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-P="python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 10 --preheat 60 --no-cpu-baseline --params $PSET"
+P="python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 10 --preheat 60 --no-cpu-baseline --no-secondary --params $PSET"
 i=0
 for pmc in "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64" \
            "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM"; do

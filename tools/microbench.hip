@@ -120,6 +120,35 @@ F32_KERNEL(k_cvt_ubyte, "v_cvt_f32_ubyte0 %0, %0", "v_cvt_f32_ubyte0 %1, %1", "v
 F32_KERNEL(k_floor_f32, "v_floor_f32 %0, %0", "v_floor_f32 %1, %1", "v_floor_f32 %2, %2", "v_floor_f32 %3, %3", "v_floor_f32 %4, %4", "v_floor_f32 %5, %5", "v_floor_f32 %6, %6", "v_floor_f32 %7, %7")
 F32_KERNEL(k_frexp_mant, "v_frexp_mant_f32 %0, %0", "v_frexp_mant_f32 %1, %1", "v_frexp_mant_f32 %2, %2", "v_frexp_mant_f32 %3, %3", "v_frexp_mant_f32 %4, %4", "v_frexp_mant_f32 %5, %5", "v_frexp_mant_f32 %6, %6", "v_frexp_mant_f32 %7, %7")
 
+F32_KERNEL(k_or_b32, "v_or_b32 %0, %8, %0", "v_or_b32 %1, %8, %1", "v_or_b32 %2, %8, %2", "v_or_b32 %3, %8, %3", "v_or_b32 %4, %8, %4", "v_or_b32 %5, %8, %5", "v_or_b32 %6, %8, %6", "v_or_b32 %7, %8, %7")
+F32_KERNEL(k_sub_f32, "v_sub_f32 %0, %8, %0", "v_sub_f32 %1, %8, %1", "v_sub_f32 %2, %8, %2", "v_sub_f32 %3, %8, %3", "v_sub_f32 %4, %8, %4", "v_sub_f32 %5, %8, %5", "v_sub_f32 %6, %8, %6", "v_sub_f32 %7, %8, %7")
+F32_KERNEL(k_lshl_b32, "v_lshlrev_b32 %0, 3, %0", "v_lshlrev_b32 %1, 3, %1", "v_lshlrev_b32 %2, 3, %2", "v_lshlrev_b32 %3, 3, %3", "v_lshlrev_b32 %4, 3, %4", "v_lshlrev_b32 %5, 3, %5", "v_lshlrev_b32 %6, 3, %6", "v_lshlrev_b32 %7, 3, %7")
+F32_KERNEL(k_ashr_i32, "v_ashrrev_i32 %0, 3, %0", "v_ashrrev_i32 %1, 3, %1", "v_ashrrev_i32 %2, 3, %2", "v_ashrrev_i32 %3, 3, %3", "v_ashrrev_i32 %4, 3, %4", "v_ashrrev_i32 %5, 3, %5", "v_ashrrev_i32 %6, 3, %6", "v_ashrrev_i32 %7, 3, %7")
+F32_KERNEL(k_mul_e64, "v_mul_f32_e64 %0, %8, %0", "v_mul_f32_e64 %1, %8, %1", "v_mul_f32_e64 %2, %8, %2", "v_mul_f32_e64 %3, %8, %3", "v_mul_f32_e64 %4, %8, %4", "v_mul_f32_e64 %5, %8, %5", "v_mul_f32_e64 %6, %8, %6", "v_mul_f32_e64 %7, %8, %7")
+F32_KERNEL(k_add_abs, "v_add_f32_e64 %0, |%8|, %0", "v_add_f32_e64 %1, |%8|, %1", "v_add_f32_e64 %2, |%8|, %2", "v_add_f32_e64 %3, |%8|, %3", "v_add_f32_e64 %4, |%8|, %4", "v_add_f32_e64 %5, |%8|, %5", "v_add_f32_e64 %6, |%8|, %6", "v_add_f32_e64 %7, |%8|, %7")
+F32_KERNEL(k_mul_omod, "v_mul_f32_e64 %0, %8, %0 mul:2", "v_mul_f32_e64 %1, %8, %1 mul:2", "v_mul_f32_e64 %2, %8, %2 mul:2", "v_mul_f32_e64 %3, %8, %3 mul:2", "v_mul_f32_e64 %4, %8, %4 mul:2", "v_mul_f32_e64 %5, %8, %5 mul:2", "v_mul_f32_e64 %6, %8, %6 mul:2", "v_mul_f32_e64 %7, %8, %7 mul:2")
+F32_KERNEL(k_mad_u24, "v_mad_u32_u24 %0, %0, %8, %9", "v_mad_u32_u24 %1, %1, %8, %9", "v_mad_u32_u24 %2, %2, %8, %9", "v_mad_u32_u24 %3, %3, %8, %9", "v_mad_u32_u24 %4, %4, %8, %9", "v_mad_u32_u24 %5, %5, %8, %9", "v_mad_u32_u24 %6, %6, %8, %9", "v_mad_u32_u24 %7, %7, %8, %9")
+F32_KERNEL(k_sdwa_lshl, "v_lshlrev_b32_sdwa %0, %8, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "v_lshlrev_b32_sdwa %1, %8, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "v_lshlrev_b32_sdwa %2, %8, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "v_lshlrev_b32_sdwa %3, %8, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "v_lshlrev_b32_sdwa %4, %8, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "v_lshlrev_b32_sdwa %5, %8, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "v_lshlrev_b32_sdwa %6, %8, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "v_lshlrev_b32_sdwa %7, %8, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0")
+F32_KERNEL(k_mov_sdwa, "v_mov_b32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_mov_b32_sdwa %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_mov_b32_sdwa %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_mov_b32_sdwa %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_mov_b32_sdwa %4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_mov_b32_sdwa %5, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_mov_b32_sdwa %6, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_mov_b32_sdwa %7, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+F32_KERNEL(k_cvt_pk_u16, "v_cvt_pknorm_u16_f32 %0, %0, %8", "v_cvt_pknorm_u16_f32 %1, %1, %8", "v_cvt_pknorm_u16_f32 %2, %2, %8", "v_cvt_pknorm_u16_f32 %3, %3, %8", "v_cvt_pknorm_u16_f32 %4, %4, %8", "v_cvt_pknorm_u16_f32 %5, %5, %8", "v_cvt_pknorm_u16_f32 %6, %6, %8", "v_cvt_pknorm_u16_f32 %7, %7, %8")
+F32_KERNEL(k_fract, "v_fract_f32 %0, %0", "v_fract_f32 %1, %1", "v_fract_f32 %2, %2", "v_fract_f32 %3, %3", "v_fract_f32 %4, %4", "v_fract_f32 %5, %5", "v_fract_f32 %6, %6", "v_fract_f32 %7, %7")
+F32_KERNEL(k_rndne, "v_rndne_f32 %0, %0", "v_rndne_f32 %1, %1", "v_rndne_f32 %2, %2", "v_rndne_f32 %3, %3", "v_rndne_f32 %4, %4", "v_rndne_f32 %5, %5", "v_rndne_f32 %6, %6", "v_rndne_f32 %7, %7")
+F32_KERNEL(k_min3, "v_min3_f32 %0, %0, %8, %9", "v_min3_f32 %1, %1, %8, %9", "v_min3_f32 %2, %2, %8, %9", "v_min3_f32 %3, %3, %8, %9", "v_min3_f32 %4, %4, %8, %9", "v_min3_f32 %5, %5, %8, %9", "v_min3_f32 %6, %6, %8, %9", "v_min3_f32 %7, %7, %8, %9")
+F32_KERNEL(k_xad, "v_xad_u32 %0, %0, %8, %9", "v_xad_u32 %1, %1, %8, %9", "v_xad_u32 %2, %2, %8, %9", "v_xad_u32 %3, %3, %8, %9", "v_xad_u32 %4, %4, %8, %9", "v_xad_u32 %5, %5, %8, %9", "v_xad_u32 %6, %6, %8, %9", "v_xad_u32 %7, %7, %8, %9")
+F32_KERNEL(k_add_lshl, "v_add_lshl_u32 %0, %0, %8, 3", "v_add_lshl_u32 %1, %1, %8, 3", "v_add_lshl_u32 %2, %2, %8, 3", "v_add_lshl_u32 %3, %3, %8, 3", "v_add_lshl_u32 %4, %4, %8, 3", "v_add_lshl_u32 %5, %5, %8, 3", "v_add_lshl_u32 %6, %6, %8, 3", "v_add_lshl_u32 %7, %7, %8, 3")
+F32_KERNEL(k_sad, "v_sad_u32 %0, %0, %8, %9", "v_sad_u32 %1, %1, %8, %9", "v_sad_u32 %2, %2, %8, %9", "v_sad_u32 %3, %3, %8, %9", "v_sad_u32 %4, %4, %8, %9", "v_sad_u32 %5, %5, %8, %9", "v_sad_u32 %6, %6, %8, %9", "v_sad_u32 %7, %7, %8, %9")
+F32_KERNEL(k_mul_lo, "v_mul_lo_u32 %0, %0, %8", "v_mul_lo_u32 %1, %1, %8", "v_mul_lo_u32 %2, %2, %8", "v_mul_lo_u32 %3, %3, %8", "v_mul_lo_u32 %4, %4, %8", "v_mul_lo_u32 %5, %5, %8", "v_mul_lo_u32 %6, %6, %8", "v_mul_lo_u32 %7, %7, %8")
+F32_KERNEL(k_cvt_i32, "v_cvt_i32_f32 %0, %0", "v_cvt_i32_f32 %1, %1", "v_cvt_i32_f32 %2, %2", "v_cvt_i32_f32 %3, %3", "v_cvt_i32_f32 %4, %4", "v_cvt_i32_f32 %5, %5", "v_cvt_i32_f32 %6, %6", "v_cvt_i32_f32 %7, %7")
+F32_KERNEL(k_cvt_f32_i32, "v_cvt_f32_i32 %0, %0", "v_cvt_f32_i32 %1, %1", "v_cvt_f32_i32 %2, %2", "v_cvt_f32_i32 %3, %3", "v_cvt_f32_i32 %4, %4", "v_cvt_f32_i32 %5, %5", "v_cvt_f32_i32 %6, %6", "v_cvt_f32_i32 %7, %7")
+F32_KERNEL(k_dpp_quad, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+F32_KERNEL(k_dpp_rowshr, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf")
+F32_KERNEL(k_mul_dpp, "v_mul_f32_dpp %0, %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mul_f32_dpp %1, %1, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mul_f32_dpp %2, %2, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mul_f32_dpp %3, %3, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mul_f32_dpp %4, %4, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mul_f32_dpp %5, %5, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mul_f32_dpp %6, %6, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mul_f32_dpp %7, %7, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+F32_KERNEL(k_subrev, "v_subrev_f32 %0, %8, %0", "v_subrev_f32 %1, %8, %1", "v_subrev_f32 %2, %8, %2", "v_subrev_f32 %3, %8, %3", "v_subrev_f32 %4, %8, %4", "v_subrev_f32 %5, %8, %5", "v_subrev_f32 %6, %8, %6", "v_subrev_f32 %7, %8, %7")
+F32_KERNEL(k_mac_2lit, "v_fmamk_f32 %0, %8, 0x3f9e3779, %0", "v_fmamk_f32 %1, %8, 0x3f9e3779, %1", "v_fmamk_f32 %2, %8, 0x3f9e3779, %2", "v_fmamk_f32 %3, %8, 0x3f9e3779, %3", "v_fmamk_f32 %4, %8, 0x3f9e3779, %4", "v_fmamk_f32 %5, %8, 0x3f9e3779, %5", "v_fmamk_f32 %6, %8, 0x3f9e3779, %6", "v_fmamk_f32 %7, %8, 0x3f9e3779, %7")
+F32_KERNEL(k_cmp_u32, "v_cmp_lt_u32 vcc, %8, %0", "v_cmp_lt_u32 vcc, %8, %1", "v_cmp_lt_u32 vcc, %8, %2", "v_cmp_lt_u32 vcc, %8, %3", "v_cmp_lt_u32 vcc, %8, %4", "v_cmp_lt_u32 vcc, %8, %5", "v_cmp_lt_u32 vcc, %8, %6", "v_cmp_lt_u32 vcc, %8, %7")
+F32_KERNEL(k_cmp_class, "v_cmp_class_f32 vcc, %0, %8", "v_cmp_class_f32 vcc, %1, %8", "v_cmp_class_f32 vcc, %2, %8", "v_cmp_class_f32 vcc, %3, %8", "v_cmp_class_f32 vcc, %4, %8", "v_cmp_class_f32 vcc, %5, %8", "v_cmp_class_f32 vcc, %6, %8", "v_cmp_class_f32 vcc, %7, %8")
+F32_KERNEL(k_swap, "v_swap_b32 %0, %0", "v_swap_b32 %1, %1", "v_swap_b32 %2, %2", "v_swap_b32 %3, %3", "v_swap_b32 %4, %4", "v_swap_b32 %5, %5", "v_swap_b32 %6, %6", "v_swap_b32 %7, %7")
+
 // 64-bit operand kernels: accumulators are doubles / float2
 #define F64_KERNEL(NAME, T, INIT, I0, I1, I2, I3, I4, I5, I6, I7)                                           \
     __global__ void NAME(float* out, long long* cyc, T x, T y)                                               \
@@ -268,6 +297,37 @@ int main(int argc, char**)
     (void)hipMemcpy(hclk, dclk, 24, hipMemcpyDeviceToHost);
     printf("s_memtime ticks per s_memrealtime tick (100 MHz): %.3f -> s_memtime at %.1f MHz\n", (double)hclk[0] / hclk[1], 100.0 * hclk[0] / hclk[1]);
     printf("per wave-instruction per SIMD: s_memtime ticks | wall ns, at waves/SIMD = 1, 2, 4, 8\n");
+    if (argc > 3) {   // fourth batch (r03): which opcodes / encodings issue at the full rate
+        run("v_or_b32", k_or_b32, 0, 1.0001f, 0.5f);
+        run("v_sub_f32", k_sub_f32, 0, 1.0001f, 0.5f);
+        run("v_subrev_f32", k_subrev, 0, 1.0001f, 0.5f);
+        run("v_lshlrev_b32", k_lshl_b32, 0, 1.0001f, 0.5f);
+        run("v_ashrrev_i32", k_ashr_i32, 0, 1.0001f, 0.5f);
+        run("v_mul_f32 e64", k_mul_e64, 0, 1.0001f, 0.5f);
+        run("v_add_f32 |abs|", k_add_abs, 0, 1.0001f, 0.5f);
+        run("v_mul_f32 mul:2", k_mul_omod, 0, 1.0001f, 0.5f);
+        run("v_fmamk_f32", k_mac_2lit, 0, 1.0001f, 0.5f);
+        run("v_mad_u32_u24", k_mad_u24, 0, 1.0001f, 0.5f);
+        run("v_lshl sdwa", k_sdwa_lshl, 0, 1.0001f, 0.5f);
+        run("v_mov sdwa", k_mov_sdwa, 0, 1.0001f, 0.5f);
+        run("v_cvt_pknorm", k_cvt_pk_u16, 0, 1.0001f, 0.5f);
+        run("v_fract_f32", k_fract, 0, 1.0001f, 0.5f);
+        run("v_rndne_f32", k_rndne, 0, 1.0001f, 0.5f);
+        run("v_min3_f32", k_min3, 0, 1.0001f, 0.5f);
+        run("v_xad_u32", k_xad, 0, 1.0001f, 0.5f);
+        run("v_add_lshl_u32", k_add_lshl, 0, 1.0001f, 0.5f);
+        run("v_sad_u32", k_sad, 0, 1.0001f, 0.5f);
+        run("v_mul_lo_u32", k_mul_lo, 0, 1.0001f, 0.5f);
+        run("v_cvt_i32_f32", k_cvt_i32, 0, 1.0001f, 0.5f);
+        run("v_cvt_f32_i32", k_cvt_f32_i32, 0, 1.0001f, 0.5f);
+        run("dpp quad_perm", k_dpp_quad, 0, 1.0001f, 0.5f);
+        run("dpp row_shr", k_dpp_rowshr, 0, 1.0001f, 0.5f);
+        run("v_mul_f32 dpp", k_mul_dpp, 0, 1.0001f, 0.5f);
+        run("v_cmp_lt_u32", k_cmp_u32, 0, 1.0001f, 0.5f);
+        run("v_cmp_class", k_cmp_class, 0, 1.0001f, 0.5f);
+        run("v_swap_b32", k_swap, 0, 1.0001f, 0.5f);
+        return 0;
+    }
     if (argc > 2) {   // third batch (r02): candidates for replacing half-rate selects / shuffles
         run("v_bfi_b32", k_bfi_b32, 0, 1.0001f, 0.5f);
         run("v_xor_b32", k_xor_b32, 0, 1.0001f, 0.5f);

@@ -38,6 +38,74 @@ __global__ __launch_bounds__(256) void k_strips(unsigned char* out)
     }
 }
 
+// pairs: a wave owns a 128-pixel strip (2 KiB per row); lane l writes pixels 2l and 2l + 1 with TWO instructions, each of
+// which covers every other 16 bytes of the 2 KiB (what a lane that owns two adjacent Bayer columns would store)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_pairs(unsigned char* out)
+{
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, lane = threadIdx.x & 63;
+    const uint32_t strips = (W + 127) / 128, segs = H / 32;
+    for (uint32_t item = wave; item < strips * segs; item += nw) {
+        const uint32_t seg = item / strips, strip = item - seg * strips;
+        for (uint32_t r = 0; r < 32; ++r)
+            for (int s = 0; s < 2; ++s) {
+                const size_t col = (size_t)strip * 128 + lane * 2 + s;
+                if (col < (size_t)W) {
+                    v4u* p = reinterpret_cast<v4u*>(out + (size_t)(seg * 32 + r) * ROWB + col * 16);
+                    if (NT) __builtin_nontemporal_store(v4u{1, 2, 3, 4}, p);
+                    else *p = v4u{1, 2, 3, 4};
+                }
+            }
+    }
+}
+// the pairs pattern through raw buffer stores with each cache-policy combination (aux: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
+__global__ __launch_bounds__(256) void k_pairs_aux(unsigned char* out)
+{
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, lane = threadIdx.x & 63;
+    const uint32_t strips = (W + 127) / 128, segs = H / 32;
+    for (uint32_t item = wave; item < strips * segs; item += nw) {
+        const uint32_t seg = item / strips, strip = item - seg * strips;
+        for (uint32_t r = 0; r < 32; ++r) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)(seg * 32 + r) * ROWB, 0, (int)ROWB, 0x00020000);
+            for (int s = 0; s < 2; ++s)
+                __builtin_amdgcn_raw_buffer_store_b128(v4u{1, 2, 3, 4}, rs, (strip * 128 + lane * 2 + s) * 16, 0, AUX);
+        }
+    }
+}
+// swapped: what v_permlane32_swap leaves: ONE instruction covers a whole KiB, but lanes 0..31 hold its even pixels and
+// lanes 32..63 its odd ones (two instructions per 2-KiB row piece)
+template <int AUX>
+__global__ __launch_bounds__(256) void k_swapped(unsigned char* out)
+{
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, lane = threadIdx.x & 63;
+    const uint32_t strips = (W + 127) / 128, segs = H / 32;
+    const uint32_t px = lane < 32 ? 2 * lane : 2 * (lane - 32) + 1;
+    for (uint32_t item = wave; item < strips * segs; item += nw) {
+        const uint32_t seg = item / strips, strip = item - seg * strips;
+        for (uint32_t r = 0; r < 32; ++r) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)(seg * 32 + r) * ROWB, 0, (int)ROWB, 0x00020000);
+            for (int s = 0; s < 2; ++s)
+                __builtin_amdgcn_raw_buffer_store_b128(v4u{1, 2, 3, 4}, rs, (strip * 128 + s * 64 + px) * 16, 0, AUX);
+        }
+    }
+}
+// halves: the same 2 KiB per row, but instruction 1 writes its first KiB and instruction 2 its second (whole lines each)
+__global__ __launch_bounds__(256) void k_halves(unsigned char* out)
+{
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, lane = threadIdx.x & 63;
+    const uint32_t strips = (W + 127) / 128, segs = H / 32;
+    for (uint32_t item = wave; item < strips * segs; item += nw) {
+        const uint32_t seg = item / strips, strip = item - seg * strips;
+        for (uint32_t r = 0; r < 32; ++r)
+            for (int s = 0; s < 2; ++s) {
+                const size_t col = (size_t)strip * 128 + s * 64 + lane;
+                if (col < (size_t)W)
+                    __builtin_nontemporal_store(v4u{1, 2, 3, 4}, reinterpret_cast<v4u*>(out + (size_t)(seg * 32 + r) * ROWB + col * 16));
+            }
+    }
+}
+
 template <class F>
 static void timeit(const char* name, F launch)
 {
@@ -63,5 +131,18 @@ int main()
     timeit("strips", [&] { hipLaunchKernelGGL(k_strips<1>, dim3(grid), dim3(256), 0, 0, buf); });
     timeit("strips2", [&] { hipLaunchKernelGGL(k_strips<2>, dim3(grid), dim3(256), 0, 0, buf); });
     timeit("strips4", [&] { hipLaunchKernelGGL(k_strips<4>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("halves", [&] { hipLaunchKernelGGL(k_halves, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs nt", [&] { hipLaunchKernelGGL(k_pairs<true>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs", [&] { hipLaunchKernelGGL(k_pairs<false>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("swapped nt", [&] { hipLaunchKernelGGL(k_swapped<2>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("swapped", [&] { hipLaunchKernelGGL(k_swapped<0>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs aux0", [&] { hipLaunchKernelGGL(k_pairs_aux<0>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs sc0", [&] { hipLaunchKernelGGL(k_pairs_aux<1>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs nt", [&] { hipLaunchKernelGGL(k_pairs_aux<2>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs sc0nt", [&] { hipLaunchKernelGGL(k_pairs_aux<3>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs sc1", [&] { hipLaunchKernelGGL(k_pairs_aux<16>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs sc0sc1", [&] { hipLaunchKernelGGL(k_pairs_aux<17>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs ntsc1", [&] { hipLaunchKernelGGL(k_pairs_aux<18>, dim3(grid), dim3(256), 0, 0, buf); });
+    timeit("pairs all3", [&] { hipLaunchKernelGGL(k_pairs_aux<19>, dim3(grid), dim3(256), 0, 0, buf); });
     return 0;
 }
