@@ -194,14 +194,15 @@ constexpr uint32_t out_bpp() { return (OUTFMT == OUT_RGBA_F32 || OUTFMT == OUT_R
 
 // one pixel at byte offset `off` of the buffer `rs` (offsets at or past its num_records are dropped by the hardware)
 template <int OUTFMT>
-__device__ __forceinline__ void store_px_buf(__amdgpu_buffer_rsrc_t rs, uint32_t off, float r, float g, float b)
+__device__ __forceinline__ void store_px_buf(__amdgpu_buffer_rsrc_t rs, uint32_t off, float r, float g, float b,
+                                             uint32_t alpha = 0x3f800000u)  // the bits of 1.0f (a register of the caller's, or the literal)
 {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef uint32_t v3u __attribute__((ext_vector_type(3)));
     if (OUTFMT == OUT_RGBA_F32) {
         // nontemporal (aux bit 1): the frame is written once and never re-read by the kernel; measured on MI355X the
         // demosaic kernel goes from 4.2 to 5.7 TB/s with it (profiles/r01_experiments.md)
-        __builtin_amdgcn_raw_buffer_store_b128(v4u{f2bits(r), f2bits(g), f2bits(b), 0x3f800000u}, rs, off, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{f2bits(r), f2bits(g), f2bits(b), alpha}, rs, off, 0, 2);
     } else if (OUTFMT == OUT_RGBA_F32_PLAIN) {
         __builtin_amdgcn_raw_buffer_store_b128(v4u{f2bits(r), f2bits(g), f2bits(b), 0x3f800000u}, rs, off, 0, 0);
     } else if (OUTFMT == OUT_RGB_F32) {  // image.rs:202-277
@@ -612,7 +613,7 @@ template <int MODE, bool LDS_LUT, int OUTFMT, bool VIGN>
 __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (&b)[2], int row, const int (&col)[2],
                                           int colF, const TileGeom& g, const DeviceEdit& ed, const DevLuts<LDS_LUT>& luts,
                                           const LdsTabs& T, void* out, const float (&vcx2)[2], float vcy2, uint32_t lds_mp,
-                                          uint32_t dead_lo, uint32_t dead_hi)
+                                          uint32_t dead_lo, uint32_t dead_hi, const uint32_t (&alpha)[2])
 {
     const int W = (int)g.width, rows = (int)g.rows;
     // wave-uniform: the virtual rows above / below a band, and the rows a PART_EDGES launch leaves to the interior's
@@ -643,8 +644,10 @@ __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (
     // a column left of the frame (x0 = -1 for CFA layouts that start on a G column) or right of it wraps to / lies at an
     // offset beyond the row descriptor's num_records: dropped by the hardware's range check
     const uint32_t offF = (uint32_t)colF * BPP;
-    store_px_buf<OUTFMT>(rs, offF, bits2f(sr[0]), bits2f(sg[0]), bits2f(sb[0]));
-    store_px_buf<OUTFMT>(rs, offF + 64u * BPP, bits2f(sr[1]), bits2f(sg[1]), bits2f(sb[1]));
+    // alpha: two launch-long registers that hold 1.0f, one per store — as a literal the compiler rebuilds the whole
+    // 128-bit operand around it for every store (two v_mov_b64 and three v_mov_b32 each)
+    store_px_buf<OUTFMT>(rs, offF, bits2f(sr[0]), bits2f(sg[0]), bits2f(sb[0]), alpha[0]);
+    store_px_buf<OUTFMT>(rs, offF + 64u * BPP, bits2f(sr[1]), bits2f(sg[1]), bits2f(sb[1]), alpha[1]);
 }
 
 template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool VIGN = false>
@@ -695,6 +698,8 @@ void k_hp(const StreamArgs a)
     };
     // pixel of the first 64 of a strip that this lane stores after the half-wave swap (hp_finish)
     const int pxF = lane < 32 ? 2 * lane : 2 * (lane - 32) + 1;
+    uint32_t alpha[2] = {0x3f800000u, 0x3f800000u};
+    asm volatile("" : "+v"(alpha[0]), "+v"(alpha[1]));
 
     for (uint32_t vitem = wave; vitem < a.nvirt; vitem += nwaves) {
         uint32_t item = vitem, sub = 0, sub_pairs = a.seg_pairs;
@@ -782,7 +787,7 @@ void k_hp(const StreamArgs a)
                 cam_to_linear(camv, t2.va, cross, diag, r[0], gg[0], b[0]);
                 cam_to_linear(camv, horiz, t2.vb, vert, r[1], gg[1], b[1]);
                 hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[0],
-                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi);
+                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha);
             }
             {   // row 1 (window position 3): a = G site on the B row, b = B site
                 const float s1a = t2.va + t4.va, s1b = t2.vb + t4.vb;
@@ -795,7 +800,7 @@ void k_hp(const StreamArgs a)
                 cam_to_linear(camv, vert, t3.va, horiz, r[0], gg[0], b[0]);
                 cam_to_linear(camv, diag, cross, t3.vb, r[1], gg[1], b[1]);
                 hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row + 1, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[1],
-                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi);
+                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha);
             }
             // slide the window down two rows
             w0a = t2.va; w0b = t2.vb;
@@ -959,6 +964,9 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         cy[k] = p / (uint32_t)W;
         cx[k] = p - cy[k] * (uint32_t)W;
     }
+    // 1.0f for the alpha channel in two launch-long registers, one per store of an iteration (see hp_finish)
+    uint32_t alpha[2] = {0x3f800000u, 0x3f800000u};
+    asm volatile("" : "+v"(alpha[0]), "+v"(alpha[1]));
     for (; base < npix; base += stride) {
         float r[2], g[2], b[2];
         uint32_t active[2] = {1u, 1u};
@@ -1011,7 +1019,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<unsigned char*>(a.out) + (size_t)base * BPP, 0, (int)(span(base) * BPP), RPF_BUFFER_RSRC_FLAGS);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) store_px_buf<OUTFMT>(ors, ((uint32_t)k * NT + tid) * BPP, r[k], g[k], b[k]);
+        for (int k = 0; k < 2; ++k) store_px_buf<OUTFMT>(ors, ((uint32_t)k * NT + tid) * BPP, r[k], g[k], b[k], alpha[k]);
         if (coords && !LENS) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
