@@ -251,12 +251,15 @@ RPF_HD void mask_rgb_stage(const MaskParams& PP, uint32_t m, const Luts& luts, f
                 x *= highlight_gain; y *= highlight_gain; z *= highlight_gain;
             }
         }
-        if (P.flags & MF_BLACK) {
+        // Black and white points: x + 0.0f == x for every x the chain can hold here (never -0: each row of the camera matrix
+        // has a positive coefficient), so with run-time flags the two stages run unconditionally, like white balance
+        // and exposure above — tested per launch the compiler if-converts them into three additions AND three selects.
+        if (STATIC_FLAGS < 0 || (P.flags & MF_BLACK)) {
             const float t1 = 1.0f - highlight_mask;
             const float add = PP.black * (t1 * t1);  // pow(1 - t, 2.0) correctly rounded
             x += add; y += add; z += add;
         }
-        if (P.flags & MF_WHITE) {
+        if (STATIC_FLAGS < 0 || (P.flags & MF_WHITE)) {
             const float add = PP.white * (highlight_mask * highlight_mask);
             x += add; y += add; z += add;
         }

@@ -70,8 +70,25 @@ __device__ __forceinline__ float chain_main_light(const LdsTabs& T, const MaskPa
 struct LdsMaskParams {
     const MaskParams* karg;
     uint32_t lds_base;
+    const MaskParams* main = nullptr;  // k_hp: "main"'s parameters with the floats in vector registers (pin_main_params)
 };
-__device__ __forceinline__ const MaskParams& mask_params_main(const LdsMaskParams& s) { return s.karg[0]; }
+__device__ __forceinline__ const MaskParams& mask_params_main(const LdsMaskParams& s) { return s.main ? *s.main : s.karg[0]; }
+// "main" alone (the single-mask kernels of k_hp): the same pinned copy
+struct PinnedMain {
+    const MaskParams* main;
+};
+__device__ __forceinline__ const MaskParams& mask_params_main(const PinnedMain& s) { return *s.main; }
+__device__ __forceinline__ const MaskParams& mask_params_user(const PinnedMain& s, uint32_t) { return *s.main; }  // never called: num_masks == 1
+// "main"'s tone / white-balance factors feed up to 33 f32 multiplications and additions per pixel in the run-time-flag
+// kernels, and an SGPR operand halves the f32 rate: nine vector registers for the launch (the flag word stays scalar:
+// it steers wave-uniform branches).  The pristine kernels never read them and the registers are dead there.
+__device__ __forceinline__ MaskParams pin_main_params(const MaskParams& k)
+{
+    MaskParams P = k;
+    asm volatile("" : "+v"(P.r_gain), "+v"(P.g_gain), "+v"(P.b_gain), "+v"(P.exposure_mul), "+v"(P.shadow), "+v"(P.highlight),
+                 "+v"(P.black), "+v"(P.white), "+v"(P.contrast_c));
+    return P;
+}
 __device__ __forceinline__ MaskParams mask_params_user(const LdsMaskParams& s, uint32_t m)
 {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -246,14 +263,17 @@ __device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T
 // The edit chain on a pixel pair in the depth of specialisation MODE names (see the enum above).
 template <int MODE, class Luts>
 __device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (&b)[2], const uint32_t (&active)[2],
-                                          const DeviceEdit& ed, const Luts& luts, const LdsTabs& T, uint32_t lds_mp)
+                                          const DeviceEdit& ed, const Luts& luts, const LdsTabs& T, uint32_t lds_mp,
+                                          const MaskParams* mainv = nullptr)  // pin_main_params' copy (k_hp)
 {
     if (MODE == MODE_DEVELOP_1P) {
         edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, ed.mp, 1u, luts, T);
     } else if (MODE == MODE_DEVELOP_1H) {
-        edit_chain<2, true>(r, gg, b, active, ed.mp, 1u, luts, T);
+        if (mainv) edit_chain<2, true>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
+        else edit_chain<2, true>(r, gg, b, active, ed.mp, 1u, luts, T);
     } else if (MODE == MODE_DEVELOP_1) {
-        edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
+        if (mainv) edit_chain<2>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
+        else edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
     } else if (MODE == MODE_DEVELOP_SEQ) {
         for (int k = 0; k < 2; ++k) {
             float r1[1] = {r[k]}, g1[1] = {gg[k]}, b1[1] = {b[k]};
@@ -266,7 +286,7 @@ __device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (
     } else if (MODE == MODE_DEVELOP_MP) {
         edit_chain<2, false, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
     } else if (lds_mp != 0xffffffffu) {
-        edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
+        edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp, mainv}, ed.num_masks, luts, T);
     } else {
         edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
     }
@@ -613,7 +633,7 @@ template <int MODE, bool LDS_LUT, int OUTFMT, bool VIGN>
 __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (&b)[2], int row, const int (&col)[2],
                                           int colF, const TileGeom& g, const DeviceEdit& ed, const DevLuts<LDS_LUT>& luts,
                                           const LdsTabs& T, void* out, const float (&vcx2)[2], float vcy2, uint32_t lds_mp,
-                                          uint32_t dead_lo, uint32_t dead_hi, const uint32_t (&alpha)[2])
+                                          uint32_t dead_lo, uint32_t dead_hi, const uint32_t (&alpha)[2], const MaskParams* mainv)
 {
     const int W = (int)g.width, rows = (int)g.rows;
     // wave-uniform: the virtual rows above / below a band, and the rows a PART_EDGES launch leaves to the interior's
@@ -628,7 +648,7 @@ __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (
     if (!mode_single(MODE) && ed.num_masks > 1)
         for (int k = 0; k < 2; ++k)  // col[] is clamped into the frame: dead lanes read a valid entry
             active[k] = active_masks(ed, row_live ? (size_t)row * W + col[k] : 0, (size_t)rows * W);
-    run_chain<MODE>(r, gg, b, active, ed, luts, T, lds_mp);
+    run_chain<MODE>(r, gg, b, active, ed, luts, T, lds_mp, mainv);
     // A row that is not stored gets an EMPTY descriptor (num_records 0: the hardware drops the stores) instead of a
     // branch around them: behind a branch the compiler also sinks half of the chain, and the join then needs
     // s_waitcnt vmcnt(0) — a drain of the row's own stores — because the chain's gathers are still in flight on the
@@ -700,6 +720,7 @@ void k_hp(const StreamArgs a)
     const int pxF = lane < 32 ? 2 * lane : 2 * (lane - 32) + 1;
     uint32_t alpha[2] = {0x3f800000u, 0x3f800000u};
     asm volatile("" : "+v"(alpha[0]), "+v"(alpha[1]));
+    const MaskParams mainv = pin_main_params(a.ed.mp[0]);
 
     for (uint32_t vitem = wave; vitem < a.nvirt; vitem += nwaves) {
         uint32_t item = vitem, sub = 0, sub_pairs = a.seg_pairs;
@@ -787,7 +808,7 @@ void k_hp(const StreamArgs a)
                 cam_to_linear(camv, t2.va, cross, diag, r[0], gg[0], b[0]);
                 cam_to_linear(camv, horiz, t2.vb, vert, r[1], gg[1], b[1]);
                 hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[0],
-                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha);
+                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha, &mainv);
             }
             {   // row 1 (window position 3): a = G site on the B row, b = B site
                 const float s1a = t2.va + t4.va, s1b = t2.vb + t4.vb;
@@ -800,7 +821,7 @@ void k_hp(const StreamArgs a)
                 cam_to_linear(camv, vert, t3.va, horiz, r[0], gg[0], b[0]);
                 cam_to_linear(camv, diag, cross, t3.vb, r[1], gg[1], b[1]);
                 hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row + 1, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[1],
-                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha);
+                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha, &mainv);
             }
             // slide the window down two rows
             w0a = t2.va; w0b = t2.vb;
