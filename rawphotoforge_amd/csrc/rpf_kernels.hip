@@ -51,12 +51,15 @@ struct LdsTabs {
     const SinCosTable& sc;
     // launch-long constants in vector registers (rpf_chain.h chain_k_*, rpf_math.h pow_c3)
     float k_gamma_lin, k_gamma_off, main_sat, main_light;
-    __device__ __forceinline__ LdsTabs(uint32_t base, const MathTables* T, const MaskParams& main)
+    // pin: hold them in vector registers (k_hp, k_apply: four waves per SIMD, 128 VGPRs); the column-per-lane kernels
+    // run five waves per SIMD on 96 and keep the values as literals / scalar operands, as before
+    __device__ __forceinline__ LdsTabs(uint32_t base, const MathTables* T, const MaskParams& main, bool pin)
         : cbrt{base + (uint32_t)offsetof(MathTables, cbrt), PowCoef<POW_CBRT>::c3},
           gamma{base + (uint32_t)offsetof(MathTables, gamma), PowCoef<POW_GAMMA>::c3}, sc(T->sc),
           k_gamma_lin(12.92f), k_gamma_off(0.055f), main_sat(main.sat_gain), main_light(main.light_gain)
     {
-        asm volatile("" : "+v"(cbrt.c3), "+v"(gamma.c3), "+v"(k_gamma_lin), "+v"(k_gamma_off), "+v"(main_sat), "+v"(main_light));
+        if (pin)
+            asm volatile("" : "+v"(cbrt.c3), "+v"(gamma.c3), "+v"(k_gamma_lin), "+v"(k_gamma_off), "+v"(main_sat), "+v"(main_light));
     }
 };
 __device__ __forceinline__ float chain_k_gamma_lin(const LdsTabs& T) { return T.k_gamma_lin; }
@@ -82,11 +85,15 @@ __device__ __forceinline__ const MaskParams& mask_params_user(const PinnedMain& 
 // "main"'s tone / white-balance factors feed up to 33 f32 multiplications and additions per pixel in the run-time-flag
 // kernels, and an SGPR operand halves the f32 rate: nine vector registers for the launch (the flag word stays scalar:
 // it steers wave-uniform branches).  The pristine kernels never read them and the registers are dead there.
+template <bool ALL>
 __device__ __forceinline__ MaskParams pin_main_params(const MaskParams& k)
 {
     MaskParams P = k;
-    asm volatile("" : "+v"(P.r_gain), "+v"(P.g_gain), "+v"(P.b_gain), "+v"(P.exposure_mul), "+v"(P.shadow), "+v"(P.highlight),
-                 "+v"(P.black), "+v"(P.white), "+v"(P.contrast_c));
+    // the white-balance gains and the exposure factor: twelve multiplications per pixel
+    asm volatile("" : "+v"(P.r_gain), "+v"(P.g_gain), "+v"(P.b_gain), "+v"(P.exposure_mul));
+    // the rest (seven operations per pixel) where the registers are there: with the vignette stage's the 128 of four
+    // waves per SIMD are used up, and a spill inside the loop costs more than the half-rate operands
+    if (ALL) asm volatile("" : "+v"(P.shadow), "+v"(P.highlight), "+v"(P.black), "+v"(P.white), "+v"(P.contrast_c));
     return P;
 }
 __device__ __forceinline__ MaskParams mask_params_user(const LdsMaskParams& s, uint32_t m)
@@ -425,7 +432,7 @@ void k_stream(const StreamArgs a)
         __syncthreads();  // the only barrier of the kernel
     }
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
-    const LdsTabs tabs(0u, T, a.ed.mp[0]);
+    const LdsTabs tabs(0u, T, a.ed.mp[0], false);
     // the u16 band as one buffer: (rows + 4) rows of W samples (run_stream checks that it is shorter than 4 GiB)
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
@@ -686,7 +693,7 @@ void k_hp(const StreamArgs a)
     if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();  // the only barrier of the kernel
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
-    const LdsTabs tabs(0u, T, a.ed.mp[0]);
+    const LdsTabs tabs(0u, T, a.ed.mp[0], true);
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
 
@@ -720,7 +727,7 @@ void k_hp(const StreamArgs a)
     const int pxF = lane < 32 ? 2 * lane : 2 * (lane - 32) + 1;
     uint32_t alpha[2] = {0x3f800000u, 0x3f800000u};
     asm volatile("" : "+v"(alpha[0]), "+v"(alpha[1]));
-    const MaskParams mainv = pin_main_params(a.ed.mp[0]);
+    const MaskParams mainv = pin_main_params<!VIGN>(a.ed.mp[0]);
 
     for (uint32_t vitem = wave; vitem < a.nvirt; vitem += nwaves) {
         uint32_t item = vitem, sub = 0, sub_pairs = a.seg_pairs;
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
         assert_lds_base(smem);
         stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     }
-    const LdsTabs tabs((uint32_t)((TILE_ELEMS * 4 + 15) & ~15), T, a.ed.mp[0]);
+    const LdsTabs tabs((uint32_t)((TILE_ELEMS * 4 + 15) & ~15), T, a.ed.mp[0], false);
     const int lx = tid & (TILE_W - 1);
     const int ly = 2 * (tid / TILE_W);
     const int lane = tid & 63;
@@ -950,7 +957,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
-    const LdsTabs tabs(0u, T, a.ed.mp[0]);
+    const LdsTabs tabs(0u, T, a.ed.mp[0], true);
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
     const uint32_t stride = gridDim.x * NT * 2;
@@ -1596,7 +1603,11 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
     // the shipped kernel is k_hp; the column-per-lane k_stream stays for A/B: variant 20, and the variants that are
     // options of its launcher (6, 8, 9, 14, 15); 7, 10, 11, 12 choose the specialisation and apply to either
-    const bool hp = cfg.variant == 0 || cfg.variant == 7 || cfg.variant == 10 || cfg.variant == 11 || cfg.variant == 12;
+    const bool hp_variant = cfg.variant == 0 || cfg.variant == 7 || cfg.variant == 10 || cfg.variant == 11 || cfg.variant == 12;
+    // ... and for launches with user masks: a mask stage is a chain of dependent LDS reads and L2 gathers per mask, and
+    // five waves per SIMD (k_stream: 93 VGPRs) hide that better than four (4 masks 0.324 vs 0.345 ms, 8 masks 0.467 vs
+    // 0.538: profiles/r03_experiments.md); variant 21 (A/B) forces k_hp there too
+    const bool hp = (hp_variant && ed.num_masks == 1) || cfg.variant == 21;
     if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
         if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // variant 12 (A/B): run-time flags also for a pristine "main"
             return run_fused<256, MODE_DEVELOP_1P, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);

@@ -10,7 +10,7 @@ if [ $rc -ne 0 ]; then grep -E "^E " $OUT/gpu_tests.log | head -20; fi
 CFGS=${BENCH_CFGS:-develop:D:0 develop:S:0 develop:G:0 develop:D:1 develop:D:2 develop:S:2 demosaic:D:0 demosaic:D:1 apply:D:0 apply:S:0}
 for cfg in $CFGS; do
   IFS=: read w p v <<< "$cfg"
-  timeout -k 10 300 python bench.py --steps 200 --warmup 20 --workload $w --params $p --variant $v --no-cpu-baseline >> $OUT/bench_variants.log 2>&1; rc=$?
+  timeout -k 10 300 python bench.py --steps 200 --warmup 20 --workload $w --params $p --variant $v --no-cpu-baseline --no-secondary >> $OUT/bench_variants.log 2>&1; rc=$?
   stop_if_killed $rc "bench $cfg"
 done
 python - <<PY
