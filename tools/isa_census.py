@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction census of a fused kernel's inner loop (one step = 128 pixels per wavefront), from the device
+"""Static instruction census of a fused kernel's inner loop (one trip = 128 or 256 pixels per wavefront), from the device
 assembly:   hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DRPF_TU=1 \
                   -mllvm -amdgpu-sched-strategy=max-ilp --cuda-device-only -S rawphotoforge_amd/csrc/rpf_kernels.hip -o k.s
             python tools/isa_census.py k.s '<mangled kernel name or a substring of it>' [...]
@@ -139,12 +139,13 @@ def main():
         valu = {k: v for k, v in cls.items() if k in COST}
         n = sum(valu.values())
         ns = sum(COST[k] * v for k, v in valu.items())
-        print(f"## `{name}` — inner loop, one step (128 pixels per wavefront)\n")
-        print("| class | instructions | ns per wave-step per SIMD at the measured issue cost |")
+        px = 256 if "k_hp" in name else 128   # k_hp walks two rows of 128 columns per trip, k_stream two rows of 64
+        print(f"## `{name}` — one trip of the inner loop = {px} pixels per wavefront\n")
+        print("| class | instructions | ns per trip per SIMD at the measured issue cost |")
         print("|---|---|---|")
         for k in sorted(valu, key=lambda k: -COST[k] * valu[k]):
             print(f"| {k} | {valu[k]} | {COST[k] * valu[k]:.0f} |")
-        print(f"| **VALU total** | **{n}** ({n / 2:.0f} per pixel) | **{ns:.0f}** |")
+        print(f"| **VALU total** | **{n}** ({n * 64 / px:.0f} per pixel; {n * 128 / px:.0f} per 128 pixels) | **{ns:.0f}** ({ns * 128 / px:.0f} per 128 pixels) |")
         for k in ("salu/smem", "lds", "vmem", "ctl"):
             print(f"| {k} | {cls.get(k, 0)} | |")
         print("\nby opcode: " + ", ".join(f"{o} {c}" for o, c in ops.most_common()) + "\n")
