@@ -1508,13 +1508,14 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
     auto items_for = [&](uint32_t sp) { return a.strips * ((total_pairs + sp - 1) / sp); };
     // Whole rounds (see run_stream): the fewest rounds R for which a strip cut into floor(R * waves / strips) equal
     // segments gives items of 4..30 row pairs; 6000 x 4000 on 4096 waves is ONE round of 4089 items of 23 pairs.
+    // (a row band of a sharded frame is a small launch — 6000 x 500 is 2.9 steps per wave — so items go down to 2 pairs)
     a.seg_pairs = 4;
     bool whole_rounds = false;
     for (uint32_t r = 1; r <= 8 && !whole_rounds; ++r) {
         const uint32_t segs = r * cap_waves / a.strips;
         if (segs == 0) continue;
         const uint32_t sp = (total_pairs + segs - 1) / segs;
-        if (sp >= 4 && sp <= 30) { a.seg_pairs = sp; whole_rounds = true; }
+        if (sp >= 2 && sp <= 30) { a.seg_pairs = sp; whole_rounds = true; }
     }
     if (!whole_rounds && items_for(16) >= 2 * cap_waves) a.seg_pairs = 16;
     a.nitems = items_for(a.seg_pairs);
@@ -1549,6 +1550,10 @@ template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
 static hipError_t run_fused(bool hp, const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                             const DeviceEdit* ed, void* d_out, hipStream_t s)
 {
+    // k_hp always as ONE 1024-thread workgroup per CU (the same four waves per SIMD as four 256-thread ones): the math
+    // tables are then staged once per CU instead of four times — 7 instead of 29 MB of L2 -> LDS traffic per launch, which
+    // is most of what a launch costs before its first pixel (variant 22, A/B: 256-thread workgroups)
+    if (hp && cfg.variant != 22) return run_hp<1024, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s);
     return hp ? run_hp<NT, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s)
               : run_stream<NT, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s);
 }
@@ -1603,7 +1608,7 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
         return run_stream<256, MODE_DEVELOP_SEQ, false, OUT_RGBA_F32>(cfg, d_cfa, raw, g, &ed, d_out, s);
     // the shipped kernel is k_hp; the column-per-lane k_stream stays for A/B: variant 20, and the variants that are
     // options of its launcher (6, 8, 9, 14, 15); 7, 10, 11, 12 choose the specialisation and apply to either
-    const bool hp_variant = cfg.variant == 0 || cfg.variant == 7 || cfg.variant == 10 || cfg.variant == 11 || cfg.variant == 12;
+    const bool hp_variant = cfg.variant == 0 || cfg.variant == 22 || cfg.variant == 7 || cfg.variant == 10 || cfg.variant == 11 || cfg.variant == 12;
     // ... and for launches with user masks: a mask stage is a chain of dependent LDS reads and L2 gathers per mask, and
     // five waves per SIMD (k_stream: 93 VGPRs) hide that better than four (4 masks 0.324 vs 0.345 ms, 8 masks 0.467 vs
     // 0.538: profiles/r03_experiments.md); variant 21 (A/B) forces k_hp there too

@@ -353,6 +353,9 @@ RPF_HD uint32_t hue_index_core(float y, float x, const Entry* hb, Entry& bd_out,
     // Straight-line code on purpose (the ENTRY is selected, not the read): written as a select around the table read, the
     // compiler turns it into a branch per pixel with the gather and its wait inside, which serialises the pair and
     // exposes the whole L2 latency.
+    // The 3/16: |v - true position| <= 0.1203 (the polynomial, swept over EVERY binary32 q = min / max in [0, 1] on the
+    // device) + 0.001 (v_rcp_f32 and the product) + 0.006 (the three reflections' roundings) and |boundary j - position j|
+    // <= 0.007, together 0.134 < 0.1875 (tests/test_gpu_math.py test_hue_candidate_error_over_every_binary32_ratio).
     const float frac = v - (vr - 8388608.0f);  // exact: v - round(v), in [-0.5, 0.5]
     const bool near = !SPARSE || __builtin_fabsf(frac) < 0.1875f;
     const Entry bd = hb[near ? j : 0u];

@@ -118,3 +118,35 @@ extern "C" int gpu_hue_index(const float* y, const float* x, uint64_t n, const d
     (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout); (void)hipFree(dhb);
     return rc;
 }
+
+// hue_candidate's error, exhaustively.  The candidate depends on the direction (x, y) only through q = min / max in
+// [0, 1] (the polynomial) and through the octant (three exact reflections about 16383.75, 32767.5, 65535, each one more
+// binary32 rounding of a value below 65536: <= 2^-8 / 2 each).  With y = q and x = 1 the device code's reciprocal is
+// exact, no reflection is taken, and the sweep visits EVERY binary32 q in [0, 1]: max |candidate - atan(q) 65535 / (2 pi)|.
+__global__ void k_hue_candidate_sweep(uint32_t lo, uint64_t n, unsigned int* max_err_bits)
+{
+    float worst = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float q = rpf::bits2f(lo + (uint32_t)i);
+        float mx;
+        const float v = rpf::hue_candidate(q, 1.0f, mx);
+        const double truth = atan((double)q) * (65535.0 / 6.283185307179586476925286766559);
+        const float e = (float)fabs((double)v - truth);
+        worst = e > worst ? e : worst;
+    }
+    atomicMax(max_err_bits, rpf::f2bits(worst));  // non-negative floats order like their bit patterns
+}
+
+extern "C" int gpu_hue_candidate_sweep(uint32_t lo_bits, uint64_t n, float* max_err)
+{
+    unsigned int* d = nullptr;
+    if (hipMalloc((void**)&d, 4) != hipSuccess) return 1;
+    (void)hipMemset(d, 0, 4);
+    hipLaunchKernelGGL(k_hue_candidate_sweep, dim3(256 * 8), dim3(256), 0, 0, lo_bits, n, d);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    unsigned int bits = 0;
+    (void)hipMemcpy(&bits, d, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    *max_err = rpf::bits2f(bits);
+    return rc;
+}

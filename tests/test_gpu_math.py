@@ -81,3 +81,27 @@ def test_hue_index_on_the_device_matches_the_oracle(checker):
             rr = radius * rng.uniform(0.5, 1.0, ang.size)
             a, b = both(rr * np.sin(ang), rr * np.cos(ang))
             assert np.array_equal(a, b), (radius, off, np.nonzero(a != b)[0][:10])
+
+
+def test_hue_candidate_error_over_every_binary32_ratio(checker):
+    """the sparse decision of hue_index (a candidate 3/16 or more away from the integer it rounds to settles
+    its side of the boundary by itself) needs |candidate - true position| + |boundary j - position j| < 0.1875, and that
+    was only sampled.  The candidate is a function of q = min / max in [0, 1] and of the octant, so it can be swept: EVERY
+    binary32 q in [0, 1] through the device code (1 065 353 217 values), then the rest bounded analytically —
+      reciprocal (1 ulp) and the product mn * rcp: the slope of the index scale in q is <= 65535 / (2 pi) = 10430 and
+        q / (1 + q^2) <= 1/2, so <= 10430 * 0.5 * 1.5 * 2^-23 = 0.001;
+      three reflections (16383.75 - v, 32767.5 - v, 65535 - v), each one rounding of a value < 65536: <= 3 * 2^-9 = 0.006;
+      boundary j against position j: 0.007 (measured over all 65536 boundaries, tests/test_math_exhaustive.py)."""
+    lib = checker
+    lib.gpu_hue_candidate_sweep.restype = C.c_int
+    lib.gpu_hue_candidate_sweep.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_float)]
+    worst = 0.0
+    one = 0x3f800000
+    for lo in range(0, one + 1, 1 << 28):
+        n = min(1 << 28, one + 1 - lo)
+        e = C.c_float(0)
+        assert lib.gpu_hue_candidate_sweep(lo, n, C.byref(e)) == 0
+        worst = max(worst, e.value)
+    total = worst + 0.001 + 0.006 + 0.007
+    print(f"hue candidate: max polynomial error {worst:.5f} index units over every binary32 q in [0, 1]; total bound {total:.5f} < 0.1875")
+    assert worst < 0.17 and total < 0.1875, (worst, total)
