@@ -278,17 +278,20 @@ int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_edito
  * per process and GPU: with lens_distortion = 0 a pixel needs its own sample and a 5x5 CFA neighbourhood, so a band needs
  * the two Bayer rows above and below it from its neighbours and nothing else.  An rpf_shard is one rank's end of that
  * exchange: an RCCL communicator (librccl is loaded at rpf_shard_create, not linked: a single-GPU host never touches it),
- * a side stream and two events.  One call per frame, rpf_shard_develop, enqueues the whole step and returns:
+ * a side stream and two events.  One call per frame, rpf_shard_develop, enqueues the whole step and returns.  By default
+ * that is, on `stream`: ncclGroupStart, ncclSend / ncclRecv of the 2-row halos with the ranks above and below, ncclGroupEnd,
+ * then the fused kernel over the band.  With RPF_SHARD_OVERLAP the exchange (xGMI latency, not bandwidth: 2 x 2 x width
+ * bytes per direction) hides behind the rows that need no halo:
  *
  *     stream:  gate ----> fused kernel, interior rows (they read no halo row) ------------------> wait(done)
- *     side:    wait(gate) -> ncclGroupStart, ncclSend/ncclRecv of the 2-row halos with the ranks above and below,
- *              ncclGroupEnd -> fused kernel, the band's first and last 8 rows (one launch) -> done
+ *     side:    wait(gate) -> the same ncclGroup -> fused kernel, the band's first and last 8 rows (one launch) -> done
  *
- * so the exchange (xGMI latency, not bandwidth: 2 x 2 x width bytes per direction) hides behind the interior.  The band
+ * which pays two cross-stream dependencies per step: measured on one MI355X they cost more than the exchange of a
+ * 6000 x 500 or 12000 x 1000 band, hence not the default; it is there for larger bands.  The band
  * buffer has the layout of rpf_dev_develop: (rows + 4) rows, row r = frame row y0 - 2 + r; the exchange writes rows 0, 1
  * and rows + 2, rows + 3 (never at a frame edge: the kernel mirrors there) and sends rows 2, 3 and rows, rows + 1.  The
  * editor is the band's (rpf_editor_create_for_tile with the band's y0 / rows; masks are band-sized).  Bands shorter than
- * 32 rows are developed by one launch after the exchange.  lens_distortion != 0 does not shard (whole-frame resample):
+ * 32 rows are always developed by one launch after the exchange.  lens_distortion != 0 does not shard (whole-frame resample):
  * refused, as by rpf_dev_develop.
  *
  * rpf_shard_unique_id: ncclGetUniqueId — call on ONE rank and hand the 128 bytes to the others (any channel: a file, a
@@ -301,7 +304,7 @@ int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_edito
 typedef struct rpf_shard rpf_shard;
 enum {
     RPF_SHARD_NO_EXCHANGE = 1u, /* halo rows are already in place (the caller exchanged or pre-filled them) */
-    RPF_SHARD_NO_OVERLAP = 2u,  /* exchange on `stream`, then ONE launch over the band */
+    RPF_SHARD_OVERLAP = 2u,     /* hide the exchange behind the interior rows (side stream, one edge-rows launch) */
     RPF_SHARD_FORCE_SPLIT = 4u  /* interior / edges schedule even without neighbours (measuring its cost on one GPU) */
 };
 int rpf_shard_unique_id(uint8_t id[RPF_SHARD_ID_BYTES]);

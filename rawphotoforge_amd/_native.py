@@ -37,7 +37,7 @@ FLAVOUR_ACTIVE, FLAVOUR_GODOT_LEGACY = 0, 1
 PACK_MSB_FIRST, PACK_LSB_FIRST, PACK_MIPI = 0, 1, 2
 CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
 SHARD_ID_BYTES = 128
-SHARD_NO_EXCHANGE, SHARD_NO_OVERLAP, SHARD_FORCE_SPLIT = 1, 2, 4
+SHARD_NO_EXCHANGE, SHARD_OVERLAP, SHARD_FORCE_SPLIT = 1, 2, 4
 
 
 class RawParams(C.Structure):

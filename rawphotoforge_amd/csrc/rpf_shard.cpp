@@ -3,10 +3,12 @@
 // frame is cut into row bands, one process and GPU per band.
 //
 // MI355X-first: xGMI is point-to-point and a halo is 2 rows (24-48 KB), so the exchange is latency, not bandwidth.  It is
-// one ncclGroup of neighbour sends / receives on a high-priority side stream, issued BEFORE the interior launch so that
-// RCCL's few workgroups get their CU slots ahead of the fused kernel's persistent ones, and the rows that need the halos
-// (first and last 8 of the band) are ONE small launch behind it.  Everything a step needs is enqueued by one C call:
-// no Python, no per-step allocation, no host synchronisation.
+// one ncclGroup of neighbour sends / receives, by default on the caller's stream in front of ONE launch over the band; with
+// RPF_SHARD_OVERLAP on a high-priority side stream, issued BEFORE the interior launch so that RCCL's few workgroups get their
+// CU slots ahead of the fused kernel's persistent ones, with the rows that need the halos (first and last 8 of the band) as
+// ONE small launch behind it (measured: the two cross-stream dependencies of that schedule cost more than the exchange of a
+// 500- or 1000-row band).  Everything a step needs is enqueued by one C call: no Python, no per-step
+// allocation, no host synchronisation.
 //
 // librccl is loaded with dlopen at rpf_shard_create (world > 1, or a self-exchange rehearsal): librpf_hip.so does not
 // link it, so a single-GPU host (the reference's only configuration) never maps the 300-MB library.
@@ -290,7 +292,7 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
     const BandLaunch b{e, band, (uint32_t)row_stride, bits, order, make_raw_params(*raw), d_out, out_format};
     const uint32_t rows = e->geom.rows;
     const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
-    const bool split = ((exchange && !(flags & RPF_SHARD_NO_OVERLAP)) || (flags & RPF_SHARD_FORCE_SPLIT)) &&
+    const bool split = ((exchange && (flags & RPF_SHARD_OVERLAP)) || (flags & RPF_SHARD_FORCE_SPLIT)) &&
                        rows >= 4 * 2 * EDGE_PAIRS;
     if (!split) {
         if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, cur))) return rc;

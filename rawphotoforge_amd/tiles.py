@@ -222,8 +222,8 @@ class BandDeveloper:
 
 class ShardedDeveloper:
     """One rank's band through the library's own sharded step (include/rpf.h rpf_shard_develop): ONE C call per frame
-    enqueues the gate, the RCCL halo exchange on the library's side stream, the interior launch and the single
-    edge-rows launch.  The measured N > 1 configuration of bench.py; BandDeveloper (torch.distributed) remains as
+    enqueues the RCCL halo exchange and the band's launch — or, with overlap=True (RPF_SHARD_OVERLAP), the gate, the exchange
+    on the library's side stream, the interior launch and the single edge-rows launch.  The measured N > 1 configuration of bench.py; BandDeveloper (torch.distributed) remains as
     the rehearsal path for gloo and as the fallback when RCCL cannot be initialised inside the library.
 
     `shard`: a rawphotoforge_amd.Shard (None: a one-rank shard without neighbours is created).
@@ -231,7 +231,7 @@ class ShardedDeveloper:
     """
 
     def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, shard=None, packed=None,
-                 overlap=True, force_split=False):
+                 overlap=False, force_split=False):
         from . import _native as N
         from .editor import PhotoEditor, Shard
 
@@ -241,7 +241,7 @@ class ShardedDeveloper:
         self.w, self.rows = frame_width, rows
         self.ed = PhotoEditor.for_tile(gpu, frame_width, frame_height, y0, rows)
         configure(self.ed)
-        self.flags = (0 if overlap else N.SHARD_NO_OVERLAP) | (N.SHARD_FORCE_SPLIT if force_split else 0)
+        self.flags = (N.SHARD_OVERLAP if overlap else 0) | (N.SHARD_FORCE_SPLIT if force_split else 0)
         self._no_exchange = N.SHARD_NO_EXCHANGE
         info = self.shard.info()
         neighbours = info["up"] >= 0 or info["down"] >= 0
