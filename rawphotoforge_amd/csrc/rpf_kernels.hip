@@ -158,6 +158,38 @@ struct DevLuts {
 };
 
 // ---------------------------------------------------------------------------
+// Issue priority that falls with a wave's progress through its share of the launch.
+//
+// The SIMD's arbiter serves its resident waves by priority, then AGE: at equal priority the oldest wave runs nearly
+// unimpeded and the youngest gets what is left.  In a persistent kernel whose waves start together with equal shares that
+// makes them finish one after the other, and the SIMD ends the launch with three, two, one wave — which cannot fill its
+// issue slots.  That tail was the "fixed ~10 us" of a fused launch (tools/band_sweep.py) and 5 % of a 6000x4000 frame.
+// Here a wave lowers its priority as it advances, in eighths of its share (3, 2, 1, 0, 3, 2, 1, 0: a wave that is ahead by
+// less than half of its share yields to the ones behind, except for the eighth after the wrap), so the waves of a SIMD
+// stay together and finish together.  Measured: set D 0.1672 -> 0.1594 ms, set S 0.2070 -> 0.1950 (profiles/r03_experiments.md).
+// All state is wave-uniform (scalar registers); s_setprio takes an immediate, hence the switch.
+// ---------------------------------------------------------------------------
+struct ProgressPrio {
+    uint32_t total, acc, k;
+    __device__ __forceinline__ explicit ProgressPrio(uint32_t total_steps) : total(total_steps ? total_steps : 1u), acc(0), k(0)
+    {
+        __builtin_amdgcn_s_setprio(3);
+    }
+    __device__ __forceinline__ void step_done()  // k = floor(8 * steps done / total) without a division
+    {
+        acc += 8u;
+        if (acc < total) return;
+        do { acc -= total; ++k; } while (acc >= total);
+        switch (k & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
 // DPP wavefront shifts (gfx9 family: wave_shr:1 = 0x138, wave_shl:1 = 0x130)
 // ---------------------------------------------------------------------------
 // lane L receives v of lane L-1; lane 0 keeps `edge`
@@ -467,6 +499,10 @@ void k_stream(const StreamArgs a)
 
     // Every item (64 columns x 2*seg_pairs rows) costs the same number of instructions whatever the
     // image holds, so the items are dealt round-robin: wave-uniform loop, no queue.
+    // (this wave's share in steps, for the progress priority: whole items seg_pairs each, tail sub-items one)
+    ProgressPrio prio(MODE == MODE_DEMOSAIC || wave >= a.nvirt ? 0u
+                      : (wave < a.tail_start ? (a.tail_start - wave + nwaves - 1) / nwaves * a.seg_pairs : 0u) +
+                        (a.nvirt > a.tail_start ? (a.nvirt - max(wave, a.tail_start) + nwaves - 1) / nwaves : 0u));
     for (uint32_t vitem = wave; vitem < a.nvirt; vitem += nwaves) {
         uint32_t item = vitem, sub = 0, sub_pairs = a.seg_pairs;
         if (vitem >= a.tail_start) {
@@ -591,6 +627,7 @@ void k_stream(const StreamArgs a)
                                                              vcy2_bot, MULTI ? LDS_MP : 0xffffffffu);
             // slide the window down two rows
             w0 = t2.v; t1 = t3; t2 = t4; t3 = t5;
+            if (MODE != MODE_DEMOSAIC) prio.step_done();
         }
     }
 }
@@ -728,6 +765,8 @@ void k_hp(const StreamArgs a)
     uint32_t alpha[2] = {0x3f800000u, 0x3f800000u};
     asm volatile("" : "+v"(alpha[0]), "+v"(alpha[1]));
     const MaskParams mainv = pin_main_params<!VIGN>(a.ed.mp[0]);
+    // this wave's share of the launch, in steps (items dealt round-robin; a tail sub-item counts as a whole item)
+    ProgressPrio prio(wave < a.nvirt ? (a.nvirt - wave + nwaves - 1) / nwaves * a.seg_pairs : 0u);
 
     for (uint32_t vitem = wave; vitem < a.nvirt; vitem += nwaves) {
         uint32_t item = vitem, sub = 0, sub_pairs = a.seg_pairs;
@@ -833,6 +872,7 @@ void k_hp(const StreamArgs a)
             // slide the window down two rows
             w0a = t2.va; w0b = t2.vb;
             t1 = t3; t2 = t4; t3 = t5;
+            prio.step_done();
         }
     }
 }
@@ -995,6 +1035,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     // 1.0f for the alpha channel in two launch-long registers, one per store of an iteration (see hp_finish)
     uint32_t alpha[2] = {0x3f800000u, 0x3f800000u};
     asm volatile("" : "+v"(alpha[0]), "+v"(alpha[1]));
+    ProgressPrio prio(base < npix ? (npix - base + stride - 1) / stride : 0u);  // this workgroup's iterations
     for (; base < npix; base += stride) {
         float r[2], g[2], b[2];
         uint32_t active[2] = {1u, 1u};
@@ -1057,6 +1098,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
                 cy[k] += wrap ? 1u : 0u;
             }
         }
+        prio.step_done();
     }
 }
 

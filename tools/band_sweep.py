@@ -13,7 +13,7 @@ if len(sys.argv) > 2:
 praw = R.RawParams(**syn.RAW)
 stream = torch.cuda.current_stream().cuda_stream
 W, H = 6000, 4000
-for rows in (250, 500, 1000, 2000, 4000):
+for rows in (16, 64, 128, 250, 500, 1000, 2000, 4000):
     y0 = (H - rows) // 2 & ~1
     band = tiles.make_band_buffer(syn.bayer_uniform(rows, W, seed=1), device="cuda")
     out = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda")
