@@ -147,7 +147,9 @@ def main():
     # ---- who exchanges the halos at N > 1 -------------------------------------------------------------------------
     exchange_note, shard = None, None
     if sharded:
-        want_rccl = args.exchange in ("auto", "rccl") and args.backend == "nccl"
+        # (RPF_BENCH_TRY_RCCL: try the library's communicator under gloo too — on a one-GPU box it must fail on the duplicate
+        # device and the fallback must engage: the rehearsal of this very branch)
+        want_rccl = args.exchange in ("auto", "rccl") and (args.backend == "nccl" or bool(os.environ.get("RPF_BENCH_TRY_RCCL")))
         err = ""
         if want_rccl:
             ids = [R.Shard.unique_id() if rank == 0 else None]
