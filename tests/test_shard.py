@@ -173,3 +173,31 @@ def test_shard_entry_points_refuse_null_handles(hip_lib):
     assert lib.rpf_shard_develop(None, None, None, 0, 0, 0, None, None, 0, None, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_info(None, None, None, None, None, None, 0) == N.ERR_INVALID_ARGUMENT
     lib.rpf_shard_destroy(None)   # a no-op, like free(NULL)
+
+
+@gpu_only
+def test_bench_two_ranks_rehearsal_and_rccl_fallback(tmp_path):
+    """`bench.py --gpus 2` end to end as the driver launches it (torch.distributed.run, one process per rank), on ONE GPU:
+    the process group over gloo, and — RPF_BENCH_TRY_RCCL — both ranks really calling rpf_shard_create with a broadcast
+    unique id.  RCCL must refuse two ranks on one device, every rank must learn of it, and the run must complete on the
+    torch.distributed exchange with the reason in the JSON line: strong scaling of THE 6000x4000 frame in two bands."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RPF_BENCH_TRY_RCCL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--preheat", "4",
+           "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["mode"] == "strong" and r["config"]["world_size"] == 2
+    assert r["config"]["backend"] == "gloo" and "REHEARSAL" in r["config"]["workload"] and "ONE 6000x4000 frame" in r["config"]["workload"]
+    assert [x["band"] for x in r["config"]["ranks"]] == [[0, 2000], [2000, 2000]]
+    assert "fallback" in r["config"]["exchange"] and "ncclCommInitRank" in r["config"]["exchange"]
+    assert r["value"] > 0 and abs(r["ms_per_step"] - 24.0 / r["value"] * 1e3) < 1e-2 * r["ms_per_step"]
+    assert "secondary" not in r and "cpu_baseline" not in r
