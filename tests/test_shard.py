@@ -89,6 +89,29 @@ def test_split_schedule_with_user_masks_and_odd_rows(gpu):
 
 
 @gpu_only
+@pytest.mark.parametrize("pattern", [O.CFA_RGGB, O.CFA_BGGR, O.CFA_GRBG, O.CFA_GBRG])
+def test_split_schedule_on_every_cfa_phase_and_odd_bands(gpu, pattern):
+    """The horizontal-pair kernel starts its strips on an R column and its steps on an R row: for CFA layouts that begin with
+    G or B, and for bands whose first row is odd, a strip's first column / a band's first step is virtual, and the
+    edge-rows launch's segments straddle the rows they must leave to the interior launch.  Interior + edges must still
+    write every pixel of the band exactly once, with the oracle's bits (single mask: k_hp; ragged width)."""
+    torch = pytest.importorskip("torch")
+    h, w = 211, 333
+    cfa = util.bayer_uniform(h, w, seed=40 + pattern)
+    rp = O.RawParams(cfa_pattern=pattern, black=(500, 520, 530, 510), wb=(2.1, 1.0, 1.02, 1.6))
+    spec = syn.PARAM_SETS["S"]
+    want = O.develop(cfa, rp, [util.oracle_params(spec)])
+    for y0, rows in ((0, 91), (91, 120), (33, 47), (64, 32), (1, 209)):
+        band = torch.from_numpy(_band_with_halos(cfa, y0, rows).view(np.int16)).cuda()
+        out = torch.full((rows, w, 4), -7.0, dtype=torch.float32, device="cuda")
+        sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), force_split=True)
+        assert sd.split
+        sd.step(band, out, exchange=False)
+        torch.cuda.synchronize()
+        _exact(out.cpu().numpy(), want[y0:y0 + rows])
+
+
+@gpu_only
 @pytest.mark.parametrize("overlap", [True, False])
 def test_rccl_exchange_with_itself_as_neighbour(gpu, overlap):
     """ncclCommInitRank / ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd as rpf_shard_develop issues them, on a
