@@ -74,7 +74,12 @@ def main():
                     help="N > 1: hide the exchange behind the interior rows (side stream + one edge-rows launch) instead of "
                          "exchange-then-one-launch; slower at these band sizes on the one-GPU rehearsal "
                          "(profiles/r03_host_overhead.txt), kept for larger frames")
-    ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility: exchange-then-launch is the default")
+    ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "ahead", "serial", "overlap"],
+                    help="N > 1, per step and rank: ahead = the exchange of step k + 1 is enqueued on the library's side stream "
+                         "(by its exchange thread) beside the kernel of step k — two band buffers, rpf_shard_exchange_ahead; "
+                         "serial = exchange, then one launch, on one stream; overlap = --overlap.  auto = ahead when the "
+                         "library's communicator exchanges, else serial")
     ap.add_argument("--pack", default="msb", choices=["msb", "mipi"],
                     help="develop_packed: 14-bit MSB-first bit stream (default) or MIPI CSI-2 RAW14 groups")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -82,6 +87,10 @@ def main():
     ap.add_argument("--event-stride", type=int, default=4,
                     help="HIP-event pairs (kernel duration for `roofline`) are recorded around every n-th launch of the timed "
                          "region: an event pair costs ~3.5 us of launch gap, which would otherwise be charged to `value`")
+    ap.add_argument("--rehearse-ranks", type=int, default=0, metavar="M",
+                    help="--gpus 1 only: run the band of rank M/2 of an M-rank job on this one GPU, through the N > 1 code "
+                         "path of this file, with a one-rank RCCL communicator whose rank is its own neighbour above and "
+                         "below (rpf_shard_set_neighbours(0, 0)).  `value` is this ONE band's rate; the line says REHEARSAL")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` measurements (edit set S, frame pool)")
     ap.add_argument("--secondary-steps", type=int, default=150)
     ap.add_argument("--cpu-rows", type=int, default=100)
@@ -117,17 +126,21 @@ def main():
         W, H = 12000, 8000
     if (args.strong or args.weak) and args.workload not in ("develop", "develop_packed", "demosaic"):
         raise SystemExit("--strong / --weak apply to the row-tiled workloads")
-    sharded = world > 1 and not batch
+    rehearse = args.rehearse_ranks
+    if rehearse and (world != 1 or rehearse < 2 or batch or args.workload not in ("develop", "develop_packed")):
+        raise SystemExit("--rehearse-ranks M (M >= 2) is a one-process rehearsal of the fused develop workloads")
+    vworld, vrank = (rehearse, rehearse // 2) if rehearse else (world, rank)   # the job whose band this process runs
+    sharded = vworld > 1 and not batch
     if batch:              # every rank develops whole 6000x4000 frames of its own
         mode, frame_h, (y0, rows) = "replicas", H, (0, H)
     elif args.weak:
-        mode, frame_h, (y0, rows) = "weak", H * world, (rank * H, H)
+        mode, frame_h, (y0, rows) = "weak", H * vworld, (vrank * H, H)
     else:                  # ONE frame; at N = 1 the band is the frame
-        mode, frame_h, (y0, rows) = "strong", H, tiles.split_rows(H, world)[rank]
+        mode, frame_h, (y0, rows) = "strong", H, tiles.split_rows(H, vworld)[vrank]
     praw = R.RawParams(**syn.RAW)
     spec = syn.PARAM_SETS[args.params]
     gen = syn.bayer_uniform if args.data == "U" else syn.bayer_natural
-    if mode == "strong" and world > 1:   # this rank's rows of THE frame (seed 20260630)
+    if mode == "strong" and vworld > 1:   # this rank's rows of THE frame (seed 20260630)
         cfa = np.ascontiguousarray(gen(frame_h, W, seed=20260630)[y0:y0 + rows])
     else:
         cfa = gen(rows, W, seed=20260630 + rank)          # rank 0 at N = 1: THE frame
@@ -146,7 +159,12 @@ def main():
 
     # ---- who exchanges the halos at N > 1 -------------------------------------------------------------------------
     exchange_note, shard = None, None
-    if sharded:
+    if rehearse:
+        shard = R.Shard(gpu, None, 0, 1)
+        shard.set_neighbours(0, 0)
+        exchange_note = ("REHEARSAL on one GPU: librpf_hip.so's ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd on a one-rank "
+                         "communicator, the rank its own neighbour above and below (no xGMI hop in this figure)")
+    elif sharded:
         # (RPF_BENCH_TRY_RCCL: try the library's communicator under gloo too — on a one-GPU box it must fail on the duplicate
         # device and the fallback must engage: the rehearsal of this very branch)
         want_rccl = args.exchange in ("auto", "rccl") and (args.backend == "nccl" or bool(os.environ.get("RPF_BENCH_TRY_RCCL")))
@@ -170,6 +188,13 @@ def main():
         else:
             exchange_note = "torch.distributed batch_isend_irecv from Python (tiles.BandDeveloper)" + (
                 f" — fallback, the library's communicator failed: {err}" if err else "")
+
+    schedule = "overlap" if args.overlap else args.schedule
+    if schedule == "auto":
+        schedule = "ahead" if (sharded and shard is not None and args.workload in ("develop", "develop_packed")) else "serial"
+    if schedule == "ahead" and not (sharded and shard is not None and args.workload in ("develop", "develop_packed")):
+        raise SystemExit("--schedule ahead needs the library's communicator (N > 1, --exchange rccl) and a fused develop workload")
+    args.overlap = schedule == "overlap"
 
     def make_developer(cfgfn, packed=None):
         if sharded and shard is not None:
@@ -229,6 +254,16 @@ def main():
                 e[1].record()
             nstep[0] += 1
             return
+        if args.workload in ("develop", "develop_packed") and schedule == "ahead":
+            # the next step's exchange first (side stream, beside this step's kernel), then this step's band, whose own
+            # exchange was enqueued one step ago: K steps = K exchanges + K launches, as in the serial schedule
+            d, bufs = (dev, ahead_bands) if args.workload == "develop" else (dev_packed, ahead_packed)
+            k = nstep[0]
+            d.exchange_ahead(bufs[(k + 1) & 1])
+            d.step(bufs[k & 1], out, out_fmt if args.workload == "develop" else R.OUT_RGBA_F32,
+                   out_bpp if args.workload == "develop" else 16, True, e)
+            nstep[0] += 1
+            return
         if args.workload == "develop":   # N > 1: halo exchange + band, one call
             dev.step(band, out, out_fmt, out_bpp, True, e)
             return
@@ -251,6 +286,15 @@ def main():
         if e:
             e[1].record()
 
+    ahead_bands = ahead_packed = None
+    if schedule == "ahead":   # two band buffers with the same frame; the first step's exchange goes out before any step
+        if args.workload == "develop":
+            ahead_bands = (band, band.clone())
+            dev.exchange_ahead(ahead_bands[0])
+        else:
+            ahead_packed = (packed_band, packed_band.clone())
+            dev_packed.exchange_ahead(ahead_packed[0])
+
     preheat_steps = max(0, args.preheat)
     for _ in range(preheat_steps):
         step()
@@ -269,6 +313,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if schedule == "ahead":   # the exchange that the last timed step sent ahead: consumed by one untimed step
+        k = nstep[0]
+        (dev if args.workload == "develop" else dev_packed).step(
+            (ahead_bands if args.workload == "develop" else ahead_packed)[k & 1], out, R.OUT_RGBA_F32, 16, True, None)
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -277,6 +326,8 @@ def main():
     kern_ms = sorted(e[0].elapsed_time(e[1]) for e in ev if e is not None)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     mp_per_step = (frame_h if mode == "strong" else world * rows) * W / 1e6   # the whole job: all ranks' pixels per step
+    if rehearse:
+        mp_per_step = rows * W / 1e6   # one band of the job is all that ran
     value = mp_per_step * args.steps / dt
     bpp = BYTES_PER_PX[args.workload] if args.out == "rgba" else 2 + out_bpp
     the_dev = dev_packed if args.workload == "develop_packed" else dev
@@ -299,12 +350,14 @@ def main():
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
 
-    if mode == "strong" and world > 1:
-        shape_note = f"ONE {W}x{H} frame in {world} row bands of ~{H // world} rows (strong scaling), "
-    elif mode == "weak" and world > 1:
-        shape_note = f"frame {W}x{frame_h} in {world} row bands of {rows} rows (weak scaling), "
+    if mode == "strong" and vworld > 1:
+        shape_note = f"ONE {W}x{H} frame in {vworld} row bands of ~{H // vworld} rows (strong scaling), "
+    elif mode == "weak" and vworld > 1:
+        shape_note = f"frame {W}x{frame_h} in {vworld} row bands of {rows} rows (weak scaling), "
     else:
         shape_note = ""
+    if rehearse:
+        shape_note = (f"REHEARSAL of rank {vrank} of {vworld} on ONE GPU (value = this one band's rate, not a job's): " + shape_note)
     pristine = args.params == "D" and args.masks == 1
     result = {
         "metric": "megapixels/sec full RAW→sRGB chain, 6000×4000 Bayer; % HBM roofline",   # BASELINE.json, verbatim
@@ -327,14 +380,19 @@ def main():
                          + (f", {args.masks} masks" if args.masks > 1 else "")
                          + (", REHEARSAL over gloo: ranks may share a GPU, timings are not a measurement"
                             if world > 1 and args.backend != "nccl" else "")
-                         + (", 2-row halo exchange per step, " + ("hidden behind the interior rows (edge rows launched after it)"
-                                                                  if args.overlap else "then one launch over the band")
-                            if sharded else "")),
-            "mode": mode, "input_resident": "hbm" if batch else "infinity_cache",
+                         + (", 2-row halo exchange per step, " + {
+                             "overlap": "hidden behind the interior rows (edge rows launched after it)",
+                             "serial": "then one launch over the band",
+                             "ahead": "enqueued one step ahead on the library's side stream (two band buffers: the exchange "
+                                      "of step k+1 runs beside the kernel of step k; every step is one exchange + one launch)",
+                         }[schedule] if sharded else "")),
+            "mode": mode, "schedule": schedule if sharded else None, "input_resident": "hbm" if batch else "infinity_cache",
             "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps,
             "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4), "kernel_ms_min": round(kern_ms[0], 4),
             "kernel_timing": (f"HIP-event pairs around {len(kern_ms)} of the {args.steps} timed "
-                              + ("steps (exchange + launches of one rpf_shard_develop call)" if whole_step_events else
+                              + ("steps (the wait for the exchange sent one step earlier + the launch of one rpf_shard_develop call)"
+                                 if whole_step_events and schedule == "ahead" else
+                                 "steps (exchange + launches of one rpf_shard_develop call)" if whole_step_events else
                                  "steps (prefetch pass + launch)" if batch else "launches") + f" (every {stride_ev}th)"),
             "world_size": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() if world > 1 else None),
@@ -351,7 +409,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             tr = json.load(f).get(args.workload)
-        if tr and world == 1 and args.params == "D" and args.data == "U" and not args.strong:
+        if tr and world == 1 and not rehearse and args.params == "D" and args.data == "U" and not args.strong:
             result["roofline"]["traffic"] = tr["traffic_bytes"]
             result["roofline"]["traffic_measured_in_this_run"] = False
             result["roofline"]["traffic_unit"] = "HBM bytes per launch (algorithmic: %d)" % (bpp * rows * W)
@@ -364,7 +422,8 @@ def main():
     # ---- secondary figures in the same line (N = 1, the headline workload): the kernel a user's edits dispatch (edit
     # set S: run-time flags, brightness curve in LDS, vignette) and input that really comes from HBM (a pool of frames
     # larger than the Infinity Cache, with and without the rpf_dev_prefetch pass, which is inside the timed pair)
-    if world == 1 and args.workload == "develop" and not args.no_secondary and args.masks == 1 and args.out == "rgba":
+    if (world == 1 and not rehearse and args.workload == "develop" and not args.no_secondary and args.masks == 1
+            and args.out == "rgba"):
         nsec = max(8, args.secondary_steps)
 
         def timed(fn, n):
@@ -409,7 +468,7 @@ def main():
         del frames
         result["secondary"] = sec
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not rehearse and not args.no_cpu_baseline:
         import oracle as O   # the checker, timed as the reported CPU baseline (never on the GPU path)
         from tests import util
         raw, p = util.raw_params(), util.oracle_params(spec)

@@ -315,6 +315,13 @@ int rpf_shard_set_neighbours(rpf_shard* s, int up, int down);
 int rpf_shard_info(const rpf_shard* s, int* rank, int* world, int* up, int* down, char* pci_bus_id, size_t len);
 /* the halo exchange alone, on `stream` (row_bytes = bytes of one band row; rows = band rows without the halos) */
 int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream);
+/* The same exchange on the shard's OWN side stream, ordered after what `stream` holds at the call (the band's upload, the
+ * last launch that read its halo rows), and remembered: the next rpf_shard_develop of this d_band makes its launch wait
+ * for it and exchanges nothing itself.  With two band buffers the exchange of frame k + 1 runs beside the kernel of
+ * frame k —  ahead(b1); develop(b0); ahead(b0); develop(b1); ...  — every cross-stream wait is then for something that
+ * finished a kernel ago, and a step costs the kernel alone.  At most 4 bands may be ahead at once;
+ * every rank must make the same sequence of calls (the exchanges are matched in order, as RCCL groups are). */
+int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream);
 /* One frame step of this rank.  bits = 0: d_band is the u16 band (row_stride ignored); bits in {10, 12, 14, 16}: packed
  * rows as in rpf_dev_develop_packed (their halo rows are packed rows too). */
 int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,

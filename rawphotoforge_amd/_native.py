@@ -122,6 +122,7 @@ SYMBOLS = {
     "rpf_shard_set_neighbours": (C.c_int, [_vp, C.c_int, C.c_int]),
     "rpf_shard_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int), _P(C.c_int), C.c_char_p, _sz]),
     "rpf_shard_exchange": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _vp]),
+    "rpf_shard_exchange_ahead": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _vp]),
     "rpf_shard_develop": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp,
                                     C.c_uint32]),
 }

@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
     subprocess.run(cmd, check=True)
     return LIB
 

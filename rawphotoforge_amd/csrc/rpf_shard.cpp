@@ -8,17 +8,23 @@
 // CU slots ahead of the fused kernel's persistent ones, with the rows that need the halos (first and last 8 of the band) as
 // ONE small launch behind it (measured: the two cross-stream dependencies of that schedule cost more than the exchange of a
 // 500- or 1000-row band).  Everything a step needs is enqueued by one C call: no Python, no per-step
-// allocation, no host synchronisation.
+// allocation, no host synchronisation.  For a stream of frames rpf_shard_exchange_ahead puts the NEXT band's exchange on the
+// side stream beside this band's kernel (two band buffers): its waits are for work that finished a kernel ago, the RCCL
+// group is enqueued by a thread of the shard's own, and a neighbour that runs late costs slack, not an idle GPU.
 //
 // librccl is loaded with dlopen at rpf_shard_create (world > 1, or a self-exchange rehearsal): librpf_hip.so does not
 // link it, so a single-GPU host (the reference's only configuration) never maps the 300-MB library.
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and enumerators only: every entry point is resolved with dlsym
+#include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 
 #include "rpf_internal.h"
 
@@ -106,7 +112,30 @@ struct rpf_shard {
     ncclComm_t comm = nullptr;
     hipStream_t side = nullptr;            // exchange + edge rows (highest priority)
     hipEvent_t gate = nullptr, done = nullptr;
+    unsigned event_flags = hipEventDisableTiming;
     char bus[32] = {0};
+
+    // Exchanges enqueued ahead of their band's develop call (rpf_shard_exchange_ahead).  RCCL's group costs the host
+    // ~16 us, more than half of a 500-row band's kernel: it is enqueued by a thread of the shard's own, so that the
+    // caller's thread pays an event record and a queue push per exchange.  `rccl_mu` serialises every use of the
+    // communicator (the worker's and the calling thread's, rpf_shard_exchange / the default rpf_shard_develop).
+    struct Ahead {
+        const void* band = nullptr;
+        size_t row_bytes = 0;
+        uint32_t rows = 0;
+        hipEvent_t gate = nullptr, ready = nullptr;
+        bool pending = false;   // between rpf_shard_exchange_ahead and the develop call that consumes it
+        bool enqueued = false;  // the worker has put the exchange and `ready` on the side stream
+        int rc = 0;
+        std::string error;
+    };
+    static constexpr int kAhead = 4;
+    Ahead ahead[kAhead];
+    std::mutex rccl_mu, mu;
+    std::condition_variable cv;
+    std::deque<Ahead*> work;
+    std::thread worker;
+    bool stop = false;
 };
 
 namespace {
@@ -130,6 +159,7 @@ int enqueue_exchange(rpf_shard* s, unsigned char* band, size_t row_bytes, uint32
 {
     if (s->up < 0 && s->down < 0) return RPF_OK;
     if (rows < 2) return api_fail(RPF_ERR_INVALID_ARGUMENT, "a band must have at least 2 rows to feed its neighbours' halos");
+    std::lock_guard<std::mutex> lock(s->rccl_mu);
     int rc = need_comm(s);
     if (rc) return rc;
     const Rccl* R = rccl();
@@ -169,6 +199,35 @@ hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream)
     return launch_develop(cfg, reinterpret_cast<const uint16_t*>(b.band), b.raw, b.e->geom, b.e->dev, b.out, b.out_format, stream);
 }
 
+// The shard's exchange thread: for every band handed over by rpf_shard_exchange_ahead, side stream <- wait(gate), the
+// RCCL group, record(ready).  Errors travel to the develop call that consumes the band (rpf_last_error is per thread).
+void exchange_worker(rpf_shard* s)
+{
+    (void)hipSetDevice(s->proc->device);
+    for (;;) {
+        rpf_shard::Ahead* a = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(s->mu);
+            s->cv.wait(lock, [&] { return s->stop || !s->work.empty(); });
+            if (s->work.empty()) return;  // stop, and nothing left to enqueue
+            a = s->work.front();
+            s->work.pop_front();
+        }
+        int rc = RPF_OK;
+        hipError_t he = hipStreamWaitEvent(s->side, a->gate, 0);
+        if (he != hipSuccess) rc = api_hip_fail(he, "hipStreamWaitEvent(side, gate)");
+        if (!rc) rc = enqueue_exchange(s, static_cast<unsigned char*>(const_cast<void*>(a->band)), a->row_bytes, a->rows, s->side);
+        if (!rc && (he = hipEventRecord(a->ready, s->side)) != hipSuccess) rc = api_hip_fail(he, "hipEventRecord(ready, side)");
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            a->rc = rc;
+            if (rc) a->error = rpf_last_error();
+            a->enqueued = true;
+        }
+        s->cv.notify_all();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -189,12 +248,24 @@ int rpf_shard_unique_id(uint8_t id[RPF_SHARD_ID_BYTES])
 void rpf_shard_destroy(rpf_shard* s)
 {
     if (!s) return;
+    if (s->worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            s->stop = true;
+        }
+        s->cv.notify_all();
+        s->worker.join();
+    }
     if (s->proc && hipSetDevice(s->proc->device) == hipSuccess) {
         if (s->side) (void)hipStreamSynchronize(s->side);
         const Rccl* R = s->comm ? rccl() : nullptr;
         if (R) (void)R->CommDestroy(s->comm);
         if (s->gate) (void)hipEventDestroy(s->gate);
         if (s->done) (void)hipEventDestroy(s->done);
+        for (auto& a : s->ahead) {
+            if (a.gate) (void)hipEventDestroy(a.gate);
+            if (a.ready) (void)hipEventDestroy(a.ready);
+        }
         if (s->side) (void)hipStreamDestroy(s->side);
     }
     if (s->proc) api_processor_unref(s->proc);
@@ -220,8 +291,14 @@ int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, r
     int lo = 0, hi = 0;  // numerically lower = higher priority
     if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (he == hipSuccess) he = hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, hi);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->gate, hipEventDisableTiming);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    // (RPF_SHARD_EVENT_FLAGS: extra hipEventCreateWithFlags bits for the shard's events, a measurement switch.  With
+    // hipEventDisableSystemFence a step of the overlapped schedules is ~3 us shorter on one GPU — not the default: the halo
+    // rows arrive over xGMI, and whether an agent-scope fence orders them for the launch cannot be shown on one GPU.)
+    unsigned evf = hipEventDisableTiming;
+    if (const char* v = getenv("RPF_SHARD_EVENT_FLAGS")) evf |= (unsigned)strtoul(v, nullptr, 0);
+    s->event_flags = evf;
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->gate, evf);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->done, evf);
     if (he == hipSuccess) he = hipDeviceGetPCIBusId(s->bus, (int)sizeof(s->bus), p->device);
     if (he != hipSuccess) return bail(api_hip_fail(he, "shard stream / events"));
     if (world > 1) {
@@ -267,6 +344,38 @@ int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t ro
     return enqueue_exchange(s, static_cast<unsigned char*>(d_band), row_bytes, rows, (hipStream_t)stream);
 }
 
+int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream)
+{
+    if (!s || !d_band || row_bytes == 0) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->up < 0 && s->down < 0) return RPF_OK;  // no neighbours: the develop call has nothing to wait for
+    if (rows < 2) return api_fail(RPF_ERR_INVALID_ARGUMENT, "a band must have at least 2 rows to feed its neighbours' halos");
+    HIP_TRY(hipSetDevice(s->proc->device));
+    rpf_shard::Ahead* slot = nullptr;
+    for (auto& a : s->ahead)
+        if (a.band == d_band) slot = &a;
+    for (auto& a : s->ahead)
+        if (!slot && !a.pending) slot = &a;
+    if (!slot) return api_fail(RPF_ERR_INVALID_ARGUMENT, "too many exchanges ahead of their develop calls (4 bands at most)");
+    if (slot->pending) return api_fail(RPF_ERR_INVALID_ARGUMENT, "this band already has an exchange ahead of its develop call");
+    if (!slot->gate) HIP_TRY(hipEventCreateWithFlags(&slot->gate, s->event_flags));
+    if (!slot->ready) HIP_TRY(hipEventCreateWithFlags(&slot->ready, s->event_flags));
+    // after what `stream` holds now: the band's upload and the last launch that read these halo rows
+    HIP_TRY(hipEventRecord(slot->gate, (hipStream_t)stream));
+    slot->band = d_band;
+    slot->row_bytes = row_bytes;
+    slot->rows = rows;
+    slot->pending = true;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        slot->enqueued = false;
+        slot->rc = 0;
+        s->work.push_back(slot);
+        if (!s->worker.joinable()) s->worker = std::thread(exchange_worker, s);
+    }
+    s->cv.notify_all();
+    return RPF_OK;
+}
+
 int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
                       const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags)
 {
@@ -294,6 +403,20 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
     const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
     const bool split = ((exchange && (flags & RPF_SHARD_OVERLAP)) || (flags & RPF_SHARD_FORCE_SPLIT)) &&
                        rows >= 4 * 2 * EDGE_PAIRS;
+    rpf_shard::Ahead* ahead = nullptr;
+    for (auto& a : s->ahead)
+        if (a.pending && a.band == d_band) ahead = &a;
+    if (ahead) {  // the halo rows are on their way (rpf_shard_exchange_ahead): wait for them, one launch
+        ahead->pending = false;
+        {
+            std::unique_lock<std::mutex> lock(s->mu);
+            s->cv.wait(lock, [&] { return ahead->enqueued; });
+            if (ahead->rc) return api_fail(ahead->rc, ahead->error);
+        }
+        HIP_TRY(hipStreamWaitEvent(cur, ahead->ready, 0));
+        HIP_TRY(launch_part(b, PART_ALL, cur));
+        return RPF_OK;
+    }
     if (!split) {
         if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, cur))) return rc;
         HIP_TRY(launch_part(b, PART_ALL, cur));

@@ -146,6 +146,70 @@ def test_rccl_exchange_with_itself_as_neighbour(gpu, overlap):
 
 
 @gpu_only
+def test_exchange_one_frame_ahead_on_two_band_buffers(gpu):
+    """rpf_shard_exchange_ahead: the exchange of the NEXT band goes out (side stream, the shard's exchange thread) before
+    the develop call of this one.  Two band buffers with DIFFERENT frames and garbage halos, alternating for six steps:
+    every step's output must be the oracle's for the frame in its buffer (the rank is its own neighbour: the halos are
+    the band's own first / last two rows), so an exchange that landed in the wrong buffer, too late, or not at all shows."""
+    torch = pytest.importorskip("torch")
+    w, rows = 520, 96
+    rp = util.raw_params()
+    spec = syn.PARAM_SETS["S"]
+    frames, wants, bands = [], [], []
+    for seed in (21, 22):
+        br = util.bayer_uniform(rows, w, seed=seed)
+        frame = np.concatenate([br[:2], br, br[-2:]])
+        wants.append(O.develop(frame, rp, [util.oracle_params(spec)], y0=2, rows=rows))
+        pad = np.full((rows + 4, w), 777 + seed, np.uint16)
+        pad[2:-2] = br
+        frames.append(br)
+        bands.append(torch.from_numpy(pad.view(np.int16)).cuda())
+    outs = [torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    shard = R.Shard(gpu, None, 0, 1)
+    shard.set_neighbours(0, 0)
+    sd = tiles.ShardedDeveloper(gpu, w, rows + 4, 2, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), shard=shard)
+    sd.exchange_ahead(bands[0])
+    with pytest.raises(R.InvalidArgument):   # one exchange per band and develop call
+        sd.exchange_ahead(bands[0])
+    for k in range(6):
+        if k < 5:
+            sd.exchange_ahead(bands[(k + 1) & 1])
+        outs[k & 1].fill_(-7.0)
+        sd.step(bands[k & 1], outs[k & 1])
+        if k in (0, 1, 4, 5):
+            torch.cuda.synchronize()
+            _exact(outs[k & 1].cpu().numpy(), wants[k & 1])
+    for b, br in zip(bands, frames):
+        got = b.cpu().numpy().view(np.uint16)
+        assert np.array_equal(got[:2], br[:2]) and np.array_equal(got[-2:], br[-2:])
+    # a band without an exchange ahead still exchanges inside its develop call
+    bands[0][:2] = 1
+    bands[0][-2:] = 1
+    sd.step(bands[0], outs[0])
+    torch.cuda.synchronize()
+    _exact(outs[0].cpu().numpy(), wants[0])
+    shard.close()
+
+
+@gpu_only
+def test_exchange_ahead_without_neighbours_is_a_no_op(gpu):
+    torch = pytest.importorskip("torch")
+    h, w = 64, 128
+    frame = util.bayer_uniform(h, w, seed=4)
+    rp = util.raw_params()
+    spec = syn.PARAM_SETS["D"]
+    want = O.develop(frame, rp, [util.oracle_params(spec)])
+    band = torch.from_numpy(_band_with_halos(frame, 0, h).view(np.int16)).cuda()
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    sd = tiles.ShardedDeveloper(gpu, w, h, 0, h, util.to_raw(rp), lambda e: syn.configure(e, spec))
+    sd.exchange_ahead(band)
+    sd.exchange_ahead(band)   # nothing is pending: no neighbours, nothing to wait for
+    sd.step(band, out)
+    torch.cuda.synchronize()
+    _exact(out.cpu().numpy(), want)
+
+
+@gpu_only
 def test_packed_band_through_the_sharded_step(gpu):
     """12-bit LSB-first packed rows (halo rows packed too) through interior + edge launches."""
     torch = pytest.importorskip("torch")
@@ -193,6 +257,7 @@ def test_shard_entry_points_refuse_null_handles(hip_lib):
     assert N.last_error()
     assert lib.rpf_shard_set_neighbours(None, 0, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_exchange(None, None, 0, 0, None) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_exchange_ahead(None, None, 0, 0, None) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_develop(None, None, None, 0, 0, 0, None, None, 0, None, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_info(None, None, None, None, None, None, 0) == N.ERR_INVALID_ARGUMENT
     lib.rpf_shard_destroy(None)   # a no-op, like free(NULL)
@@ -223,4 +288,31 @@ def test_bench_two_ranks_rehearsal_and_rccl_fallback(tmp_path):
     assert [x["band"] for x in r["config"]["ranks"]] == [[0, 2000], [2000, 2000]]
     assert "fallback" in r["config"]["exchange"] and "ncclCommInitRank" in r["config"]["exchange"]
     assert r["value"] > 0 and abs(r["ms_per_step"] - 24.0 / r["value"] * 1e3) < 1e-2 * r["ms_per_step"]
+    assert "secondary" not in r and "cpu_baseline" not in r
+    assert r["config"]["schedule"] == "serial"   # the exchange-ahead schedule needs the library's communicator
+
+
+@gpu_only
+@pytest.mark.parametrize("schedule", ["ahead", "serial"])
+def test_bench_sharded_code_path_rehearsed_on_one_gpu(schedule):
+    """The N > 1 branch of bench.py with the LIBRARY's communicator (what the driver's --gpus N run takes on a node),
+    rehearsed in one process: rank 4 of 8's band of THE frame, the rank its own neighbour.  The exchange-ahead schedule is
+    the default there: two band buffers, one exchange + one launch per step, one untimed step to drain."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--preheat", "5",
+           "--rehearse-ranks", "8"] + (["--schedule", "serial"] if schedule == "serial" else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert c["schedule"] == schedule and c["mode"] == "strong" and "REHEARSAL of rank 4 of 8" in c["workload"]
+    assert c["ranks"][0]["band"] == [2000, 500] and c["ranks"][0]["neighbours"] == [0, 0]
+    assert "one-rank" in c["exchange"] and r["n_gpus"] == 1
+    assert r["value"] > 0 and abs(r["ms_per_step"] - 3.0 / r["value"] * 1e3) < 1e-2 * r["ms_per_step"]
     assert "secondary" not in r and "cpu_baseline" not in r
