@@ -75,6 +75,12 @@ def main():
                          "exchange-then-one-launch; slower at these band sizes on the one-GPU rehearsal "
                          "(profiles/r03_host_overhead.txt), kept for larger frames")
     ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--halo", default="step", choices=["step", "once"],
+                    help="N > 1: step (default) = every step is a NEW frame: its halo rows are exchanged in every step; once = an "
+                         "editing session on ONE resident frame, the reference's own use (the image is loaded once, then "
+                         "apply_adjustments runs per slider move, photo-editor-web/src/lib.rs:198): the halo rows are exchanged "
+                         "before the first step and every step is the band's launch alone (RPF_SHARD_NO_EXCHANGE).  Not the "
+                         "headline: stated in config.workload")
     ap.add_argument("--schedule", default="auto", choices=["auto", "ahead", "serial", "overlap"],
                     help="N > 1, per step and rank: ahead = the exchange of step k + 1 is enqueued on the library's side stream "
                          "(by its exchange thread) beside the kernel of step k — two band buffers, rpf_shard_exchange_ahead; "
@@ -190,6 +196,11 @@ def main():
                 f" — fallback, the library's communicator failed: {err}" if err else "")
 
     schedule = "overlap" if args.overlap else args.schedule
+    halo_once = sharded and args.halo == "once"
+    if halo_once:
+        if args.workload not in ("develop", "develop_packed") or schedule not in ("auto", "serial"):
+            raise SystemExit("--halo once: a fused develop workload, no --schedule")
+        schedule = "serial"
     if schedule == "auto":
         schedule = "ahead" if (sharded and shard is not None and args.workload in ("develop", "develop_packed")) else "serial"
     if schedule == "ahead" and not (sharded and shard is not None and args.workload in ("develop", "develop_packed")):
@@ -265,10 +276,10 @@ def main():
             nstep[0] += 1
             return
         if args.workload == "develop":   # N > 1: halo exchange + band, one call
-            dev.step(band, out, out_fmt, out_bpp, True, e)
+            dev.step(band, out, out_fmt, out_bpp, not halo_once, e)
             return
         if args.workload == "develop_packed":   # the same on the packed band (its halo rows are packed rows too)
-            dev_packed.step(packed_band, out, R.OUT_RGBA_F32, 16, True, e)
+            dev_packed.step(packed_band, out, R.OUT_RGBA_F32, 16, not halo_once, e)
             return
         if sharded:
             if shard is not None:
@@ -294,6 +305,13 @@ def main():
         else:
             ahead_packed = (packed_band, packed_band.clone())
             dev_packed.exchange_ahead(ahead_packed[0])
+
+    if halo_once:   # the session's one exchange: with the frame's upload, not with every edit
+        if args.workload == "develop":
+            dev.step(band, out, out_fmt, out_bpp, True, None)
+        else:
+            dev_packed.step(packed_band, out, R.OUT_RGBA_F32, 16, True, None)
+        torch.cuda.synchronize()
 
     preheat_steps = max(0, args.preheat)
     for _ in range(preheat_steps):
@@ -380,13 +398,16 @@ def main():
                          + (f", {args.masks} masks" if args.masks > 1 else "")
                          + (", REHEARSAL over gloo: ranks may share a GPU, timings are not a measurement"
                             if world > 1 and args.backend != "nccl" else "")
-                         + (", 2-row halo exchange per step, " + {
+                         + (", EDITING SESSION on one resident frame: 2-row halo exchange once, before the first step; every "
+                            "step is the band's launch alone (not the headline mode: --halo step exchanges in every step)"
+                            if halo_once else
+                            ", 2-row halo exchange per step, " + {
                              "overlap": "hidden behind the interior rows (edge rows launched after it)",
                              "serial": "then one launch over the band",
                              "ahead": "enqueued one step ahead on the library's side stream (two band buffers: the exchange "
                                       "of step k+1 runs beside the kernel of step k; every step is one exchange + one launch)",
                          }[schedule] if sharded else "")),
-            "mode": mode, "schedule": schedule if sharded else None, "input_resident": "hbm" if batch else "infinity_cache",
+            "mode": mode, "schedule": (("none (halo once)" if halo_once else schedule) if sharded else None), "input_resident": "hbm" if batch else "infinity_cache",
             "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps,
             "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4), "kernel_ms_min": round(kern_ms[0], 4),
             "kernel_timing": (f"HIP-event pairs around {len(kern_ms)} of the {args.steps} timed "
