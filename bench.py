@@ -176,12 +176,20 @@ def main():
         want_rccl = args.exchange in ("auto", "rccl") and (args.backend == "nccl" or bool(os.environ.get("RPF_BENCH_TRY_RCCL")))
         err = ""
         if want_rccl:
-            ids = [R.Shard.unique_id() if rank == 0 else None]
+            ids = [None, ""]
+            if rank == 0:
+                try:
+                    ids[0] = R.Shard.unique_id()
+                except R.PhotoEditorError as ex:   # e.g. librccl cannot be loaded: the other ranks must hear of it
+                    ids[1] = str(ex)
             dist.broadcast_object_list(ids, src=0)
-            try:
-                shard = R.Shard(gpu, ids[0], rank, world)
-            except R.PhotoEditorError as ex:   # every rank must agree on the path: gathered below
-                err = str(ex)
+            if ids[0] is None:
+                err = ids[1]
+            else:
+                try:
+                    shard = R.Shard(gpu, ids[0], rank, world)
+                except R.PhotoEditorError as ex:   # every rank must agree on the path: gathered below
+                    err = str(ex)
             oks = [None] * world
             dist.all_gather_object(oks, err)
             if any(oks):
