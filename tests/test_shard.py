@@ -192,6 +192,25 @@ def test_exchange_one_frame_ahead_on_two_band_buffers(gpu):
 
 
 @gpu_only
+def test_exchange_ahead_slots_and_destroy_with_exchanges_pending(gpu):
+    """Four bands may be ahead at once, a fifth is refused; a shard destroyed while exchanges are pending lets its exchange
+    thread enqueue them, drains the side stream and returns (the rank is its own neighbour, so every group completes)."""
+    torch = pytest.importorskip("torch")
+    w, rows = 256, 32
+    shard = R.Shard(gpu, None, 0, 1)
+    shard.set_neighbours(0, 0)
+    bands = [torch.full((rows + 4, w), 100 + i, dtype=torch.int16, device="cuda") for i in range(5)]
+    for b in bands[:4]:
+        shard.exchange_ahead(b.data_ptr(), w * 2, rows, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(R.InvalidArgument):
+        shard.exchange_ahead(bands[4].data_ptr(), w * 2, rows, torch.cuda.current_stream().cuda_stream)
+    shard.close()
+    torch.cuda.synchronize()
+    for i, b in enumerate(bands[:4]):   # each band's halos now hold its own rows
+        assert int(b.cpu().min()) == 100 + i and int(b.cpu().max()) == 100 + i
+
+
+@gpu_only
 def test_exchange_ahead_without_neighbours_is_a_no_op(gpu):
     torch = pytest.importorskip("torch")
     h, w = 64, 128
