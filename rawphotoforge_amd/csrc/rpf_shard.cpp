@@ -365,12 +365,17 @@ int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint3
     slot->row_bytes = row_bytes;
     slot->rows = rows;
     slot->pending = true;
-    {
+    try {
         std::lock_guard<std::mutex> lock(s->mu);
         slot->enqueued = false;
         slot->rc = 0;
         s->work.push_back(slot);
         if (!s->worker.joinable()) s->worker = std::thread(exchange_worker, s);
+    } catch (...) {  // no memory for the queue node, or no thread to be had: nothing was handed over
+        std::lock_guard<std::mutex> lock(s->mu);
+        if (!s->work.empty() && s->work.back() == slot) s->work.pop_back();
+        slot->pending = false;
+        return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: could not start the shard's exchange thread");
     }
     s->cv.notify_all();
     return RPF_OK;
