@@ -278,7 +278,7 @@ def main():
             # exchange was enqueued one step ago: K steps = K exchanges + K launches, as in the serial schedule
             d, bufs = (dev, ahead_bands) if args.workload == "develop" else (dev_packed, ahead_packed)
             k = nstep[0]
-            d.exchange_ahead(bufs[(k + 1) & 1])
+            d.exchange_ahead(bufs[(k + 1) & 1], after_develop=True)   # the bands are resident: no upload to order after
             d.step(bufs[k & 1], out, out_fmt if args.workload == "develop" else R.OUT_RGBA_F32,
                    out_bpp if args.workload == "develop" else 16, True, e)
             nstep[0] += 1

@@ -307,6 +307,7 @@ enum {
     RPF_SHARD_OVERLAP = 2u,     /* hide the exchange behind the interior rows (side stream, one edge-rows launch) */
     RPF_SHARD_FORCE_SPLIT = 4u  /* interior / edges schedule even without neighbours (measuring its cost on one GPU) */
 };
+enum { RPF_SHARD_AHEAD_AFTER_DEVELOP = 1u }; /* rpf_shard_exchange_ahead flags */
 int rpf_shard_unique_id(uint8_t id[RPF_SHARD_ID_BYTES]);
 int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, rpf_shard** out);
 void rpf_shard_destroy(rpf_shard* s);
@@ -318,10 +319,16 @@ int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t ro
 /* The same exchange on the shard's OWN side stream, ordered after what `stream` holds at the call (the band's upload, the
  * last launch that read its halo rows), and remembered: the next rpf_shard_develop of this d_band makes its launch wait
  * for it and exchanges nothing itself.  With two band buffers the exchange of frame k + 1 runs beside the kernel of
- * frame k —  ahead(b1); develop(b0); ahead(b0); develop(b1); ...  — every cross-stream wait is then for something that
- * finished a kernel ago, and a step costs the kernel alone.  At most 4 bands may be ahead at once;
- * every rank must make the same sequence of calls (the exchanges are matched in order, as RCCL groups are). */
-int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream);
+ * frame k —  ahead(b1); develop(b0); ahead(b0); develop(b1); ...  — and a neighbour that runs late costs slack instead of
+ * an idle GPU.  At most 4 bands may be ahead at once; every rank must make the same sequence of
+ * calls (the exchanges are matched in order, as RCCL groups are).
+ * flags = RPF_SHARD_AHEAD_AFTER_DEVELOP: the band's own rows are already in place (nothing on `stream` still writes
+ * them), so the exchange only has to follow the shard's most recent rpf_shard_develop launch, the last reader of this
+ * buffer's halo rows.  That launch's own completion signal is then the gate and nothing is recorded on `stream`: one
+ * packet less between two launches, 3-4 us per step on a 6000 x 500 band.  When the shard's last develop call was not a
+ * single launch that exchanged or waited for an exchange (none yet, RPF_SHARD_NO_EXCHANGE, the split schedule) it falls
+ * back to the ordering above. */
+int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream, uint32_t flags);
 /* One frame step of this rank.  bits = 0: d_band is the u16 band (row_stride ignored); bits in {10, 12, 14, 16}: packed
  * rows as in rpf_dev_develop_packed (their halo rows are packed rows too). */
 int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,

@@ -23,6 +23,7 @@
 //   * every store is a nontemporal global_store_dwordx4, one aligned KiB per wave-instruction.
 // Pointwise/stencil path: HBM-bound by construction, no MFMA.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <string.h>
 
 #include <atomic>
@@ -1410,6 +1411,16 @@ static hipError_t interior_of(const TileGeom& g, const DeviceEdit& ed, int out_f
     return hipSuccess;
 }
 
+// A fused develop launch; with cfg.stop_event its completion signal is that event (no marker packet behind the kernel).
+template <class K, class A>
+static inline void launch_fused(const LaunchCfg& cfg, K kernel, uint32_t grid, int nt, size_t lds, hipStream_t s, const A& a)
+{
+    if (cfg.stop_event)
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(nt), lds, s, nullptr, static_cast<hipEvent_t>(cfg.stop_event), 0, a);
+    else
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(nt), lds, s, a);
+}
+
 struct PackedRows {  // bit-packed input of the fused kernel (bits == 0: d_cfa is a u16 plane)
     uint32_t bits, row_stride, lsb;
 };
@@ -1510,7 +1521,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
         const uint32_t cap = (uint32_t)cfg.num_cus * blocks_per_cu;
         if (grid > cap) grid = cap;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
+    launch_fused(cfg, kernel, grid, NT, lds, s, a);
     return hipGetLastError();
 }
 
@@ -1583,7 +1594,7 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
             a.nvirt = a.tail_start + (a.nitems - a.tail_start) * a.seg_pairs;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
+    launch_fused(cfg, kernel, grid, NT, lds, s, a);
     return hipGetLastError();
 }
 
@@ -1618,7 +1629,7 @@ static hipError_t run_tile(const LaunchCfg& cfg, const uint16_t* d_cfa, const Ra
     if (e != hipSuccess) return e;
     uint32_t grid = (uint32_t)cfg.num_cus * (uint32_t)blocks_per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds, s, a);
+    launch_fused(cfg, kernel, grid, NT, lds, s, a);
     return hipGetLastError();
 }
 

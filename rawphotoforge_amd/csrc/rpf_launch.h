@@ -45,6 +45,9 @@ struct LaunchCfg {
     int num_cus;
     int variant;  // 0 default; see rpf_kernels.hip
     int part = PART_ALL;  // fused develop launches only
+    // fused develop launches only: an event that becomes the launch's own completion signal (hipExtLaunchKernelGGL's
+    // stopEvent) — what a later cross-stream wait can name without a marker packet behind the kernel
+    void* stop_event = nullptr;
 };
 
 // d_cfa: (rows + 4) x width u16, row r = frame row y0 - 2 + r

@@ -124,6 +124,7 @@ struct rpf_shard {
         size_t row_bytes = 0;
         uint32_t rows = 0;
         hipEvent_t gate = nullptr, ready = nullptr;
+        hipEvent_t wait_for = nullptr;  // what the side stream waits for: `gate`, or a develop launch's completion signal
         bool pending = false;   // between rpf_shard_exchange_ahead and the develop call that consumes it
         bool enqueued = false;  // the worker has put the exchange and `ready` on the side stream
         int rc = 0;
@@ -131,6 +132,12 @@ struct rpf_shard {
     };
     static constexpr int kAhead = 4;
     Ahead ahead[kAhead];
+    // Completion signals of the develop launches (hipExtLaunchKernelGGL's stopEvent), rotating: what
+    // RPF_SHARD_AHEAD_AFTER_DEVELOP gates an exchange on without a marker packet on the caller's stream.
+    static constexpr int kDone = 4;
+    hipEvent_t launch_done[kDone] = {nullptr, nullptr, nullptr, nullptr};
+    int launch_i = -1;  // the most recent one in use; -1: the last develop call left none
+    bool want_launch_signal = false;  // set by the first AFTER_DEVELOP request: a signalled launch costs ~2 us more
     std::mutex rccl_mu, mu;
     std::condition_variable cv;
     std::deque<Ahead*> work;
@@ -189,10 +196,11 @@ struct BandLaunch {
     int out_format;
 };
 
-hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream)
+hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream, hipEvent_t stop_event = nullptr)
 {
     LaunchCfg cfg = cfg_of(b.e->proc);
     cfg.part = part;
+    cfg.stop_event = stop_event;
     if (b.bits)
         return launch_develop_packed(cfg, b.band, b.row_stride, b.bits, b.order, b.raw, b.e->geom, b.e->dev, b.out, b.out_format,
                                      stream);
@@ -214,7 +222,7 @@ void exchange_worker(rpf_shard* s)
             s->work.pop_front();
         }
         int rc = RPF_OK;
-        hipError_t he = hipStreamWaitEvent(s->side, a->gate, 0);
+        hipError_t he = hipStreamWaitEvent(s->side, a->wait_for, 0);
         if (he != hipSuccess) rc = api_hip_fail(he, "hipStreamWaitEvent(side, gate)");
         if (!rc) rc = enqueue_exchange(s, static_cast<unsigned char*>(const_cast<void*>(a->band)), a->row_bytes, a->rows, s->side);
         if (!rc && (he = hipEventRecord(a->ready, s->side)) != hipSuccess) rc = api_hip_fail(he, "hipEventRecord(ready, side)");
@@ -262,6 +270,8 @@ void rpf_shard_destroy(rpf_shard* s)
         if (R) (void)R->CommDestroy(s->comm);
         if (s->gate) (void)hipEventDestroy(s->gate);
         if (s->done) (void)hipEventDestroy(s->done);
+        for (auto& e : s->launch_done)
+            if (e) (void)hipEventDestroy(e);
         for (auto& a : s->ahead) {
             if (a.gate) (void)hipEventDestroy(a.gate);
             if (a.ready) (void)hipEventDestroy(a.ready);
@@ -297,6 +307,8 @@ int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, r
     unsigned evf = hipEventDisableTiming;
     if (const char* v = getenv("RPF_SHARD_EVENT_FLAGS")) evf |= (unsigned)strtoul(v, nullptr, 0);
     s->event_flags = evf;
+    for (auto& e : s->launch_done)
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e, evf);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&s->gate, evf);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&s->done, evf);
     if (he == hipSuccess) he = hipDeviceGetPCIBusId(s->bus, (int)sizeof(s->bus), p->device);
@@ -344,7 +356,7 @@ int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t ro
     return enqueue_exchange(s, static_cast<unsigned char*>(d_band), row_bytes, rows, (hipStream_t)stream);
 }
 
-int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream)
+int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream, uint32_t flags)
 {
     if (!s || !d_band || row_bytes == 0) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
     if (s->up < 0 && s->down < 0) return RPF_OK;  // no neighbours: the develop call has nothing to wait for
@@ -359,8 +371,15 @@ int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint3
     if (slot->pending) return api_fail(RPF_ERR_INVALID_ARGUMENT, "this band already has an exchange ahead of its develop call");
     if (!slot->gate) HIP_TRY(hipEventCreateWithFlags(&slot->gate, s->event_flags));
     if (!slot->ready) HIP_TRY(hipEventCreateWithFlags(&slot->ready, s->event_flags));
-    // after what `stream` holds now: the band's upload and the last launch that read these halo rows
-    HIP_TRY(hipEventRecord(slot->gate, (hipStream_t)stream));
+    if (flags & RPF_SHARD_AHEAD_AFTER_DEVELOP) s->want_launch_signal = true;
+    if ((flags & RPF_SHARD_AHEAD_AFTER_DEVELOP) && s->launch_i >= 0) {
+        // after the shard's last develop launch, named by its own completion signal: no packet on the caller's stream
+        slot->wait_for = s->launch_done[s->launch_i];
+    } else {
+        // after what `stream` holds now: the band's upload and the last launch that read these halo rows
+        HIP_TRY(hipEventRecord(slot->gate, (hipStream_t)stream));
+        slot->wait_for = slot->gate;
+    }
     slot->band = d_band;
     slot->row_bytes = row_bytes;
     slot->rows = rows;
@@ -419,21 +438,26 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
             if (ahead->rc) return api_fail(ahead->rc, ahead->error);
         }
         HIP_TRY(hipStreamWaitEvent(cur, ahead->ready, 0));
-        HIP_TRY(launch_part(b, PART_ALL, cur));
+        s->launch_i = s->want_launch_signal ? (s->launch_i + 1) % rpf_shard::kDone : -1;
+        HIP_TRY(launch_part(b, PART_ALL, cur, s->launch_i >= 0 ? s->launch_done[s->launch_i] : nullptr));
         return RPF_OK;
     }
     if (!split) {
         if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, cur))) return rc;
-        HIP_TRY(launch_part(b, PART_ALL, cur));
+        // with a completion signal (~2 us) where a later AFTER_DEVELOP may name this launch; otherwise that orders by `stream`
+        const bool sig = exchange && s->want_launch_signal;
+        s->launch_i = sig ? (s->launch_i + 1) % rpf_shard::kDone : -1;
+        HIP_TRY(launch_part(b, PART_ALL, cur, sig ? s->launch_done[s->launch_i] : nullptr));
         return RPF_OK;
     }
     // side stream: gated on what `cur` held before this step (the band's upload, the previous step's readers of the halo
     // rows); the exchange goes first so that RCCL's workgroups are dispatched ahead of the interior's persistent ones
+    s->launch_i = -1;  // two launches, joined on `cur`: a later AFTER_DEVELOP orders by its stream
     HIP_TRY(hipEventRecord(s->gate, cur));
     HIP_TRY(hipStreamWaitEvent(s->side, s->gate, 0));
     if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, s->side))) return rc;
     HIP_TRY(launch_part(b, PART_INTERIOR, cur));
-    HIP_TRY(launch_part(b, PART_EDGES, s->side));
+    HIP_TRY(launch_part(b, PART_EDGES, s->side));  // the halo rows' reader: on the stream every exchange ahead runs on
     HIP_TRY(hipEventRecord(s->done, s->side));
     HIP_TRY(hipStreamWaitEvent(cur, s->done, 0));
     return RPF_OK;

@@ -446,10 +446,12 @@ class Shard:
     def exchange(self, d_band_ptr: int, row_bytes: int, rows: int, stream: int = 0) -> None:
         _check(N.lib().rpf_shard_exchange(self._h, C.c_void_p(d_band_ptr), row_bytes, rows, C.c_void_p(stream)))
 
-    def exchange_ahead(self, d_band_ptr: int, row_bytes: int, rows: int, stream: int = 0) -> None:
-        """The exchange on the shard's side stream, after what `stream` holds now; the next develop() of this band waits
-        for it instead of exchanging (rpf_shard_exchange_ahead)."""
-        _check(N.lib().rpf_shard_exchange_ahead(self._h, C.c_void_p(d_band_ptr), row_bytes, rows, C.c_void_p(stream)))
+    def exchange_ahead(self, d_band_ptr: int, row_bytes: int, rows: int, stream: int = 0, after_develop: bool = False) -> None:
+        """The exchange on the shard's side stream, after what `stream` holds now — or, after_develop=True
+        (RPF_SHARD_AHEAD_AFTER_DEVELOP: the band's own rows are in place), after the shard's last develop launch alone;
+        the next develop() of this band waits for it instead of exchanging (rpf_shard_exchange_ahead)."""
+        _check(N.lib().rpf_shard_exchange_ahead(self._h, C.c_void_p(d_band_ptr), row_bytes, rows, C.c_void_p(stream),
+                                                N.SHARD_AHEAD_AFTER_DEVELOP if after_develop else 0))
 
     def develop(self, editor: "PhotoEditor", d_band_ptr: int, raw, d_out_ptr: int, out_format: int = N.OUT_RGBA_F32,
                 stream: int = 0, flags: int = 0, packed=None) -> None:

@@ -252,14 +252,15 @@ class ShardedDeveloper:
     def join(self):
         """rpf_shard_develop joins the side stream itself: nothing to do (BandDeveloper API compatibility)."""
 
-    def exchange_ahead(self, band, stream=None):
-        """Start `band`'s halo exchange now, on the library's side stream (after what the stream holds at this point); the
-        next step() of this band waits for it.  With two band buffers: ahead(b1); step(b0); ahead(b0); step(b1); ..."""
+    def exchange_ahead(self, band, stream=None, after_develop=False):
+        """Start `band`'s halo exchange now, on the library's side stream (after what the stream holds at this point, or —
+        after_develop=True, the band's own rows being in place — after the shard's last develop launch alone); the next
+        step() of this band waits for it.  With two band buffers: ahead(b1); step(b0); ahead(b0); step(b1); ..."""
         if stream is None:
             import torch
             stream = torch.cuda.current_stream().cuda_stream
         row_bytes = self.packed[1] if self.packed else self.w * 2
-        self.shard.exchange_ahead(band.data_ptr(), row_bytes, self.rows, stream)
+        self.shard.exchange_ahead(band.data_ptr(), row_bytes, self.rows, stream, after_develop)
 
     def step(self, band, out, out_format=0, bytes_per_px=16, exchange=True, events=None, stream=None):
         """band: (rows + 4, W) 2-byte tensor with halo rows (packed: (rows + 4, row_stride) uint8); out: rows x W pixels.

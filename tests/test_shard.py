@@ -146,7 +146,8 @@ def test_rccl_exchange_with_itself_as_neighbour(gpu, overlap):
 
 
 @gpu_only
-def test_exchange_one_frame_ahead_on_two_band_buffers(gpu):
+@pytest.mark.parametrize("after_develop", [False, True])
+def test_exchange_one_frame_ahead_on_two_band_buffers(gpu, after_develop):
     """rpf_shard_exchange_ahead: the exchange of the NEXT band goes out (side stream, the shard's exchange thread) before
     the develop call of this one.  Two band buffers with DIFFERENT frames and garbage halos, alternating for six steps:
     every step's output must be the oracle's for the frame in its buffer (the rank is its own neighbour: the halos are
@@ -172,8 +173,8 @@ def test_exchange_one_frame_ahead_on_two_band_buffers(gpu):
     with pytest.raises(R.InvalidArgument):   # one exchange per band and develop call
         sd.exchange_ahead(bands[0])
     for k in range(6):
-        if k < 5:
-            sd.exchange_ahead(bands[(k + 1) & 1])
+        if k < 5:   # after_develop: gated on the previous step's launch itself (its completion signal), no stream marker
+            sd.exchange_ahead(bands[(k + 1) & 1], after_develop=after_develop)
         outs[k & 1].fill_(-7.0)
         sd.step(bands[k & 1], outs[k & 1])
         if k in (0, 1, 4, 5):
@@ -201,7 +202,7 @@ def test_exchange_ahead_slots_and_destroy_with_exchanges_pending(gpu):
     shard.set_neighbours(0, 0)
     bands = [torch.full((rows + 4, w), 100 + i, dtype=torch.int16, device="cuda") for i in range(5)]
     for b in bands[:4]:
-        shard.exchange_ahead(b.data_ptr(), w * 2, rows, torch.cuda.current_stream().cuda_stream)
+        shard.exchange_ahead(b.data_ptr(), w * 2, rows, torch.cuda.current_stream().cuda_stream, True)   # no launch yet: as False
     with pytest.raises(R.InvalidArgument):
         shard.exchange_ahead(bands[4].data_ptr(), w * 2, rows, torch.cuda.current_stream().cuda_stream)
     shard.close()
@@ -276,7 +277,7 @@ def test_shard_entry_points_refuse_null_handles(hip_lib):
     assert N.last_error()
     assert lib.rpf_shard_set_neighbours(None, 0, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_exchange(None, None, 0, 0, None) == N.ERR_INVALID_ARGUMENT
-    assert lib.rpf_shard_exchange_ahead(None, None, 0, 0, None) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_exchange_ahead(None, None, 0, 0, None, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_develop(None, None, None, 0, 0, 0, None, None, 0, None, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_info(None, None, None, None, None, None, 0) == N.ERR_INVALID_ARGUMENT
     lib.rpf_shard_destroy(None)   # a no-op, like free(NULL)

@@ -24,7 +24,7 @@ def run(dev, band, out, n=400, pipelined=None, **kw):
         bands = (band, pipelined)  # two band buffers: the exchange of the next one runs beside this one's kernel
         dev.exchange_ahead(bands[0])
         for k in range(m - 1):
-            dev.exchange_ahead(bands[(k + 1) & 1])
+            dev.exchange_ahead(bands[(k + 1) & 1], after_develop=True)
             dev.step(bands[k & 1], out, **kw)
         dev.step(bands[(m - 1) & 1], out, **kw)
 
