@@ -81,11 +81,14 @@ def main():
                          "apply_adjustments runs per slider move, photo-editor-web/src/lib.rs:198): the halo rows are exchanged "
                          "before the first step and every step is the band's launch alone (RPF_SHARD_NO_EXCHANGE).  Not the "
                          "headline: stated in config.workload")
-    ap.add_argument("--schedule", default="auto", choices=["auto", "ahead", "serial", "overlap"],
+    ap.add_argument("--schedule", default="auto", choices=["auto", "pingpong", "ahead", "serial", "overlap"],
                     help="N > 1, per step and rank: ahead = the exchange of step k + 1 is enqueued on the library's side stream "
                          "(by its exchange thread) beside the kernel of step k — two band buffers, rpf_shard_exchange_ahead; "
-                         "serial = exchange, then one launch, on one stream; overlap = --overlap.  auto = ahead when the "
-                         "library's communicator exchanges, else serial")
+                         "serial = exchange, then one launch, on one stream; overlap = --overlap; pingpong = TWO step pipelines that "
+                         "share nothing — two RCCL communicators (two rpf_shards), two streams, two band buffers, each shard's own "
+                         "thread enqueuing its steps (rpf_shard_develop_async), frames alternating between them: one frame's "
+                         "exchange and launch latency run beside the other frame's kernel without a cross-stream dependency.  "
+                         "auto = pingpong when the library's communicators exist, else serial")
     ap.add_argument("--pack", default="msb", choices=["msb", "mipi"],
                     help="develop_packed: 14-bit MSB-first bit stream (default) or MIPI CSI-2 RAW14 groups")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -164,10 +167,11 @@ def main():
     configure = configure_with(spec)
 
     # ---- who exchanges the halos at N > 1 -------------------------------------------------------------------------
-    exchange_note, shard = None, None
+    exchange_note, shard, shard_b = None, None, None
     if rehearse:
-        shard = R.Shard(gpu, None, 0, 1)
+        shard, shard_b = R.Shard(gpu, None, 0, 1), R.Shard(gpu, None, 0, 1)   # (the second one: the pingpong schedule's)
         shard.set_neighbours(0, 0)
+        shard_b.set_neighbours(0, 0)
         exchange_note = ("REHEARSAL on one GPU: librpf_hip.so's ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd on a one-rank "
                          "communicator, the rank its own neighbour above and below (no xGMI hop in this figure)")
     elif sharded:
@@ -176,18 +180,19 @@ def main():
         want_rccl = args.exchange in ("auto", "rccl") and (args.backend == "nccl" or bool(os.environ.get("RPF_BENCH_TRY_RCCL")))
         err = ""
         if want_rccl:
-            ids = [None, ""]
+            ids = [None, "", None]   # two communicators: the pingpong schedule runs two independent step pipelines
             if rank == 0:
                 try:
-                    ids[0] = R.Shard.unique_id()
+                    ids[0], ids[2] = R.Shard.unique_id(), R.Shard.unique_id()
                 except R.PhotoEditorError as ex:   # e.g. librccl cannot be loaded: the other ranks must hear of it
-                    ids[1] = str(ex)
+                    ids[0], ids[1] = None, str(ex)
             dist.broadcast_object_list(ids, src=0)
             if ids[0] is None:
                 err = ids[1]
             else:
                 try:
                     shard = R.Shard(gpu, ids[0], rank, world)
+                    shard_b = R.Shard(gpu, ids[2], rank, world)
                 except R.PhotoEditorError as ex:   # every rank must agree on the path: gathered below
                     err = str(ex)
             oks = [None] * world
@@ -195,7 +200,7 @@ def main():
             if any(oks):
                 if args.exchange == "rccl":
                     raise SystemExit("rpf_shard_create failed: " + "; ".join(o for o in oks if o))
-                shard, err = None, "; ".join(sorted({o for o in oks if o}))
+                shard, shard_b, err = None, None, "; ".join(sorted({o for o in oks if o}))
         if shard is not None:
             exchange_note = ("librpf_hip.so: ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd on its own RCCL communicator, "
                              "one rpf_shard_develop call per step")
@@ -209,15 +214,16 @@ def main():
         if args.workload not in ("develop", "develop_packed") or schedule not in ("auto", "serial"):
             raise SystemExit("--halo once: a fused develop workload, no --schedule")
         schedule = "serial"
+    lib_sched_ok = sharded and shard is not None and args.workload in ("develop", "develop_packed")
     if schedule == "auto":
-        schedule = "ahead" if (sharded and shard is not None and args.workload in ("develop", "develop_packed")) else "serial"
-    if schedule == "ahead" and not (sharded and shard is not None and args.workload in ("develop", "develop_packed")):
-        raise SystemExit("--schedule ahead needs the library's communicator (N > 1, --exchange rccl) and a fused develop workload")
+        schedule = "pingpong" if lib_sched_ok else "serial"
+    if schedule in ("ahead", "pingpong") and not lib_sched_ok:
+        raise SystemExit(f"--schedule {schedule} needs the library's communicator (N > 1, --exchange rccl) and a fused develop workload")
     args.overlap = schedule == "overlap"
 
-    def make_developer(cfgfn, packed=None):
+    def make_developer(cfgfn, packed=None, lane_shard=None):
         if sharded and shard is not None:
-            return tiles.ShardedDeveloper(gpu, W, frame_h, y0, rows, praw, cfgfn, shard=shard, packed=packed,
+            return tiles.ShardedDeveloper(gpu, W, frame_h, y0, rows, praw, cfgfn, shard=lane_shard or shard, packed=packed,
                                           overlap=args.overlap)
         return tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, cfgfn, rank, world if sharded else 1,
                                    overlap=args.overlap, packed=packed)
@@ -273,6 +279,14 @@ def main():
                 e[1].record()
             nstep[0] += 1
             return
+        if args.workload in ("develop", "develop_packed") and schedule == "pingpong":
+            # frames alternate between two pipelines that share nothing (shard = communicator + thread, stream, band and
+            # output buffer each); the call hands the step to the shard's thread: every step is one exchange + one launch
+            lane = nstep[0] & 1
+            pp_devs[lane].step_async(pp_bands[lane], pp_outs[lane], out_fmt if args.workload == "develop" else R.OUT_RGBA_F32,
+                                     True, pp_streams[lane].cuda_stream, timed=e is not None)
+            nstep[0] += 1
+            return
         if args.workload in ("develop", "develop_packed") and schedule == "ahead":
             # the next step's exchange first (side stream, beside this step's kernel), then this step's band, whose own
             # exchange was enqueued one step ago: K steps = K exchanges + K launches, as in the serial schedule
@@ -321,20 +335,42 @@ def main():
             dev_packed.step(packed_band, out, R.OUT_RGBA_F32, 16, True, None)
         torch.cuda.synchronize()
 
+    pp_devs = pp_bands = pp_outs = pp_streams = None
+    if schedule == "pingpong":
+        if args.workload == "develop":
+            pp_devs = (dev, make_developer(configure, lane_shard=shard_b))
+            pp_bands = (band, band.clone())
+        else:
+            pp_devs = (dev_packed, make_developer(configure, packed=dev_packed.packed, lane_shard=shard_b))
+            pp_bands = (packed_band, packed_band.clone())
+        pp_outs = (out, torch.empty_like(out))
+        # DIFFERENT priorities: with equal ones the two pipelines can lock in phase (both exchanges together, then both
+        # kernels sharing the CUs: 37 instead of 25 us per step on a 6000x500 band); a priority makes that state unstable
+        pp_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0))
+
+    def drain():   # pingpong: the shards' threads have enqueued everything handed to them; then the device
+        if schedule == "pingpong":
+            shard.flush()
+            shard_b.flush()
+        torch.cuda.synchronize()
+
     preheat_steps = max(0, args.preheat)
     for _ in range(preheat_steps):
         step()
-    torch.cuda.synchronize()
+    drain()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    drain()
+    if schedule == "pingpong":   # forget the launches timed so far
+        shard.timing()
+        shard_b.timing()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    torch.cuda.synchronize()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -349,15 +385,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    kern_ms = sorted(e[0].elapsed_time(e[1]) for e in ev if e is not None)
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    if schedule == "pingpong":   # the launches' own start / completion signals, summed inside the library (RPF_SHARD_TIMED)
+        tn = [shard.timing(), shard_b.timing()]
+        kern_avg_ms = (tn[0][1] + tn[1][1]) / max(1, tn[0][0] + tn[1][0])
+        kern_ms = [kern_avg_ms] * max(1, tn[0][0] + tn[1][0])
+    else:
+        kern_ms = sorted(e[0].elapsed_time(e[1]) for e in ev if e is not None)
+        kern_avg_ms = sum(kern_ms) / len(kern_ms)
     mp_per_step = (frame_h if mode == "strong" else world * rows) * W / 1e6   # the whole job: all ranks' pixels per step
     if rehearse:
         mp_per_step = rows * W / 1e6   # one band of the job is all that ran
     value = mp_per_step * args.steps / dt
     bpp = BYTES_PER_PX[args.workload] if args.out == "rgba" else 2 + out_bpp
     the_dev = dev_packed if args.workload == "develop_packed" else dev
-    whole_step_events = sharded and shard is not None and args.workload in ("develop", "develop_packed")
+    whole_step_events = sharded and shard is not None and args.workload in ("develop", "develop_packed") and schedule != "pingpong"
     timed_rows = rows if (whole_step_events or args.workload not in ("develop", "batch", "develop_packed")) else the_dev.parts[0][1]
     achieved = bpp * timed_rows * W / (kern_avg_ms * 1e-3) / 1e9   # GB/s, algorithmic bytes of what the events bracket
 
@@ -412,6 +453,9 @@ def main():
                             ", 2-row halo exchange per step, " + {
                              "overlap": "hidden behind the interior rows (edge rows launched after it)",
                              "serial": "then one launch over the band",
+                             "pingpong": "inside each of TWO independent step pipelines (two RCCL communicators with a thread each, "
+                                         "two streams, two band and output buffers; frames alternate): one frame's exchange runs "
+                                         "beside the other frame's kernel; every step is one exchange + one launch",
                              "ahead": "enqueued one step ahead on the library's side stream (two band buffers: the exchange "
                                       "of step k+1 runs beside the kernel of step k; every step is one exchange + one launch)",
                          }[schedule] if sharded else "")),
@@ -419,7 +463,9 @@ def main():
             "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps,
             "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4), "kernel_ms_min": round(kern_ms[0], 4),
             "kernel_timing": (f"HIP-event pairs around {len(kern_ms)} of the {args.steps} timed "
-                              + ("steps (the wait for the exchange sent one step earlier + the launch of one rpf_shard_develop call)"
+                              + ("launches, by their own start / completion signals (hipExtLaunchKernelGGL events inside "
+                                 "rpf_shard_develop_async; the exchange is a kernel of RCCL's in front of each)" if schedule == "pingpong" else
+                                 "steps (the wait for the exchange sent one step earlier + the launch of one rpf_shard_develop call)"
                                  if whole_step_events and schedule == "ahead" else
                                  "steps (exchange + launches of one rpf_shard_develop call)" if whole_step_events else
                                  "steps (prefetch pass + launch)" if batch else "launches") + f" (every {stride_ev}th)"),
@@ -553,6 +599,8 @@ def main():
         if shard is not None:
             torch.cuda.synchronize()
             shard.close()
+            if shard_b is not None:
+                shard_b.close()
         dist.destroy_process_group()
 
 

@@ -308,6 +308,7 @@ enum {
     RPF_SHARD_FORCE_SPLIT = 4u  /* interior / edges schedule even without neighbours (measuring its cost on one GPU) */
 };
 enum { RPF_SHARD_AHEAD_AFTER_DEVELOP = 1u }; /* rpf_shard_exchange_ahead flags */
+enum { RPF_SHARD_TIMED = 0x100u };           /* rpf_shard_develop_async: time this step's launch (rpf_shard_timing) */
 int rpf_shard_unique_id(uint8_t id[RPF_SHARD_ID_BYTES]);
 int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, rpf_shard** out);
 void rpf_shard_destroy(rpf_shard* s);
@@ -333,6 +334,26 @@ int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint3
  * rows as in rpf_dev_develop_packed (their halo rows are packed rows too). */
 int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
                       const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags);
+/* The same step (exchange on `stream`, then one launch on `stream`), handed to the shard's own thread: the call checks its
+ * arguments, uploads pending edit state, copies what the launch needs and returns; the thread makes the RCCL calls (~16 us
+ * of host time) and the launch, in the order the steps were handed over.  Meant for a stream of frames through TWO shards —
+ * two communicators (rpf_shard_create twice, in the same order on every rank), two streams, two band buffers, frames
+ * alternating between them: the two step pipelines share nothing, so one frame's exchange, launch latency and tail run
+ * beside the other frame's kernel with no cross-stream dependency at all (which cost this runtime 4-13 us per step each:
+ * DESIGN.md section 6).  Measured on one MI355X with the rank as its own neighbour: a 6000 x 500 band 25.8 us per step —
+ * the kernel alone — against 39 for rpf_shard_develop on one stream and 35 for the exchange one frame ahead.  Give the two
+ * streams DIFFERENT priorities: with equal ones the pipelines can lock in phase (both exchanges at once, then both kernels
+ * sharing the CUs: 37 us per step); a priority makes that state unstable and they settle in antiphase.
+ * flags: RPF_SHARD_NO_EXCHANGE, RPF_SHARD_TIMED (the launch's own start / completion signals are a pair of timing events,
+ * summed up by rpf_shard_timing).  Edit state set after the call may or may not reach a step that has not run yet; output
+ * and band buffers must stay valid until the step's stream has passed it.
+ * rpf_shard_flush: blocks until every step handed over has been ENQUEUED on its stream (then hipStreamSynchronize or an
+ * event of the caller's is meaningful) and reports the first failure of such a step.
+ * rpf_shard_timing: flush, wait for the timed launches, return their number and summed duration since the last call. */
+int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
+                            const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags);
+int rpf_shard_flush(rpf_shard* s);
+int rpf_shard_timing(rpf_shard* s, uint32_t* launches, double* total_ms);
 
 /* Kernel variant selection for A/B measurements (bench.py --variant); 0 = shipped configuration.
  * fused develop: 1 = LDS-tile front end (first design), 2 = 512-thread workgroups, 3 = pixel pair sequentially,

@@ -39,6 +39,7 @@ CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
 SHARD_ID_BYTES = 128
 SHARD_NO_EXCHANGE, SHARD_OVERLAP, SHARD_FORCE_SPLIT = 1, 2, 4
 SHARD_AHEAD_AFTER_DEVELOP = 1
+SHARD_TIMED = 0x100
 
 
 class RawParams(C.Structure):
@@ -126,6 +127,10 @@ SYMBOLS = {
     "rpf_shard_exchange_ahead": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _vp, C.c_uint32]),
     "rpf_shard_develop": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp,
                                     C.c_uint32]),
+    "rpf_shard_develop_async": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp,
+                                    C.c_uint32]),
+    "rpf_shard_flush": (C.c_int, [_vp]),
+    "rpf_shard_timing": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_double)]),
 }
 
 _lib = None

@@ -1416,7 +1416,8 @@ template <class K, class A>
 static inline void launch_fused(const LaunchCfg& cfg, K kernel, uint32_t grid, int nt, size_t lds, hipStream_t s, const A& a)
 {
     if (cfg.stop_event)
-        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(nt), lds, s, nullptr, static_cast<hipEvent_t>(cfg.stop_event), 0, a);
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(nt), lds, s, static_cast<hipEvent_t>(cfg.start_event),
+                              static_cast<hipEvent_t>(cfg.stop_event), 0, a);
     else
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(nt), lds, s, a);
 }

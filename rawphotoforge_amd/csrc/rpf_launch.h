@@ -48,6 +48,7 @@ struct LaunchCfg {
     // fused develop launches only: an event that becomes the launch's own completion signal (hipExtLaunchKernelGGL's
     // stopEvent) — what a later cross-stream wait can name without a marker packet behind the kernel
     void* stop_event = nullptr;
+    void* start_event = nullptr;  // with stop_event: the pair times the kernel itself (rpf_shard_develop_async, RPF_SHARD_TIMED)
 };
 
 // d_cfa: (rows + 4) x width u16, row r = frame row y0 - 2 + r

@@ -25,6 +25,8 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
+#include <vector>
 
 #include "rpf_internal.h"
 
@@ -105,6 +107,20 @@ int nccl_fail(const Rccl* R, ncclResult_t r, const char* what, int code = RPF_ER
 
 }  // namespace
 
+namespace {
+// Everything a band's launch needs, by value: a step handed to the shard's thread outlives the call that described it.
+struct BandLaunch {
+    rpf_processor* proc;
+    TileGeom geom;
+    DeviceEdit dev;
+    const unsigned char* band;
+    uint32_t row_stride, bits, order;
+    RawParamsDev raw;
+    void* out;
+    int out_format;
+};
+}  // namespace
+
 struct rpf_shard {
     rpf_processor* proc = nullptr;
     int rank = 0, world = 1;
@@ -138,9 +154,25 @@ struct rpf_shard {
     hipEvent_t launch_done[kDone] = {nullptr, nullptr, nullptr, nullptr};
     int launch_i = -1;  // the most recent one in use; -1: the last develop call left none
     bool want_launch_signal = false;  // set by the first AFTER_DEVELOP request: a signalled launch costs ~2 us more
+    // Whole steps handed to the shard's thread (rpf_shard_develop_async): the exchange and the launch, enqueued on the
+    // step's stream by that thread.  Two shards (two communicators, two streams, two threads) alternating frames overlap
+    // one frame's exchange, launch latency and tail with the other frame's kernel without one cross-stream dependency.
+    struct Step {
+        BandLaunch b;
+        size_t row_bytes;
+        uint32_t rows;
+        bool exchange, timed;
+        hipStream_t stream;
+    };
+    struct Work { Ahead* ahead; Step* step; };
+    int in_flight = 0;           // steps handed over and not yet enqueued
+    int async_rc = 0;            // the first failure of such a step, for rpf_shard_flush
+    std::string async_error;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;  // start / stop of the timed launches since the last rpf_shard_timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_free;
     std::mutex rccl_mu, mu;
     std::condition_variable cv;
-    std::deque<Ahead*> work;
+    std::deque<Work> work;
     std::thread worker;
     bool stop = false;
 };
@@ -187,46 +219,47 @@ int enqueue_exchange(rpf_shard* s, unsigned char* band, size_t row_bytes, uint32
     return RPF_OK;
 }
 
-struct BandLaunch {
-    rpf_editor* e;
-    const unsigned char* band;
-    uint32_t row_stride, bits, order;
-    RawParamsDev raw;
-    void* out;
-    int out_format;
-};
-
-hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream, hipEvent_t stop_event = nullptr)
+hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream, hipEvent_t stop_event = nullptr,
+                       hipEvent_t start_event = nullptr)
 {
-    LaunchCfg cfg = cfg_of(b.e->proc);
+    LaunchCfg cfg = cfg_of(b.proc);
     cfg.part = part;
     cfg.stop_event = stop_event;
+    cfg.start_event = start_event;
     if (b.bits)
-        return launch_develop_packed(cfg, b.band, b.row_stride, b.bits, b.order, b.raw, b.e->geom, b.e->dev, b.out, b.out_format,
-                                     stream);
-    return launch_develop(cfg, reinterpret_cast<const uint16_t*>(b.band), b.raw, b.e->geom, b.e->dev, b.out, b.out_format, stream);
+        return launch_develop_packed(cfg, b.band, b.row_stride, b.bits, b.order, b.raw, b.geom, b.dev, b.out, b.out_format, stream);
+    return launch_develop(cfg, reinterpret_cast<const uint16_t*>(b.band), b.raw, b.geom, b.dev, b.out, b.out_format, stream);
 }
 
 // The shard's exchange thread: for every band handed over by rpf_shard_exchange_ahead, side stream <- wait(gate), the
 // RCCL group, record(ready).  Errors travel to the develop call that consumes the band (rpf_last_error is per thread).
+int run_step(rpf_shard* s, const rpf_shard::Step& t);
+
 void exchange_worker(rpf_shard* s)
 {
     (void)hipSetDevice(s->proc->device);
     for (;;) {
-        rpf_shard::Ahead* a = nullptr;
+        rpf_shard::Work w{nullptr, nullptr};
         {
             std::unique_lock<std::mutex> lock(s->mu);
             s->cv.wait(lock, [&] { return s->stop || !s->work.empty(); });
             if (s->work.empty()) return;  // stop, and nothing left to enqueue
-            a = s->work.front();
+            w = s->work.front();
             s->work.pop_front();
         }
-        int rc = RPF_OK;
-        hipError_t he = hipStreamWaitEvent(s->side, a->wait_for, 0);
-        if (he != hipSuccess) rc = api_hip_fail(he, "hipStreamWaitEvent(side, gate)");
-        if (!rc) rc = enqueue_exchange(s, static_cast<unsigned char*>(const_cast<void*>(a->band)), a->row_bytes, a->rows, s->side);
-        if (!rc && (he = hipEventRecord(a->ready, s->side)) != hipSuccess) rc = api_hip_fail(he, "hipEventRecord(ready, side)");
-        {
+        if (w.step) {  // a whole step: exchange + launch on its stream
+            const int rc = run_step(s, *w.step);
+            delete w.step;
+            std::lock_guard<std::mutex> lock(s->mu);
+            if (rc && !s->async_rc) { s->async_rc = rc; s->async_error = rpf_last_error(); }
+            --s->in_flight;
+        } else {
+            rpf_shard::Ahead* a = w.ahead;
+            int rc = RPF_OK;
+            hipError_t he = hipStreamWaitEvent(s->side, a->wait_for, 0);
+            if (he != hipSuccess) rc = api_hip_fail(he, "hipStreamWaitEvent(side, gate)");
+            if (!rc) rc = enqueue_exchange(s, static_cast<unsigned char*>(const_cast<void*>(a->band)), a->row_bytes, a->rows, s->side);
+            if (!rc && (he = hipEventRecord(a->ready, s->side)) != hipSuccess) rc = api_hip_fail(he, "hipEventRecord(ready, side)");
             std::lock_guard<std::mutex> lock(s->mu);
             a->rc = rc;
             if (rc) a->error = rpf_last_error();
@@ -234,6 +267,29 @@ void exchange_worker(rpf_shard* s)
         }
         s->cv.notify_all();
     }
+}
+
+// One step on its stream, by the shard's thread: the halo exchange, then the band's launch (timed: with a pair of events
+// as the launch's own start / completion signals — no marker packets around it).
+int run_step(rpf_shard* s, const rpf_shard::Step& t)
+{
+    int rc = RPF_OK;
+    if (t.exchange && (rc = enqueue_exchange(s, const_cast<unsigned char*>(t.b.band), t.row_bytes, t.rows, t.stream))) return rc;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (t.timed) {
+        std::lock_guard<std::mutex> lock(s->mu);
+        if (!s->timing_free.empty()) { ev = s->timing_free.back(); s->timing_free.pop_back(); }
+    }
+    if (t.timed && !ev.first) {
+        HIP_TRY(hipEventCreate(&ev.first));
+        HIP_TRY(hipEventCreate(&ev.second));
+    }
+    HIP_TRY(launch_part(t.b, PART_ALL, t.stream, ev.second, ev.first));
+    if (t.timed) {
+        std::lock_guard<std::mutex> lock(s->mu);
+        s->timing.push_back(ev);
+    }
+    return RPF_OK;
 }
 
 }  // namespace
@@ -272,6 +328,8 @@ void rpf_shard_destroy(rpf_shard* s)
         if (s->done) (void)hipEventDestroy(s->done);
         for (auto& e : s->launch_done)
             if (e) (void)hipEventDestroy(e);
+        for (auto* v : {&s->timing, &s->timing_free})
+            for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (auto& a : s->ahead) {
             if (a.gate) (void)hipEventDestroy(a.gate);
             if (a.ready) (void)hipEventDestroy(a.ready);
@@ -388,11 +446,11 @@ int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint3
         std::lock_guard<std::mutex> lock(s->mu);
         slot->enqueued = false;
         slot->rc = 0;
-        s->work.push_back(slot);
+        s->work.push_back(rpf_shard::Work{slot, nullptr});
         if (!s->worker.joinable()) s->worker = std::thread(exchange_worker, s);
     } catch (...) {  // no memory for the queue node, or no thread to be had: nothing was handed over
         std::lock_guard<std::mutex> lock(s->mu);
-        if (!s->work.empty() && s->work.back() == slot) s->work.pop_back();
+        if (!s->work.empty() && s->work.back().ahead == slot) s->work.pop_back();
         slot->pending = false;
         return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: could not start the shard's exchange thread");
     }
@@ -400,8 +458,10 @@ int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint3
     return RPF_OK;
 }
 
-int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
-                      const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags)
+namespace {
+// Argument checks and edit-state upload shared by rpf_shard_develop and rpf_shard_develop_async; fills the launch.
+int prepare_band_launch(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
+                        const rpf_raw_params* raw, void* d_out, int out_format, BandLaunch& b, size_t& row_bytes)
 {
     if (!s || !e || !d_band || !raw || !d_out) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
     if (!e->proc) return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: headless editor has no device (no CPU fallback exists)");
@@ -409,7 +469,7 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
     if (order > RPF_PACK_MIPI) return api_fail(RPF_ERR_INVALID_ARGUMENT, "unknown bit order");
     if (bits != 0 && bits != 10 && bits != 12 && bits != 14 && (bits != 16 || order == RPF_PACK_MIPI))
         return api_fail(RPF_ERR_READ_IMAGE_UNSUPPORTED_FORMAT, "Unsupported read image format: packed samples must be 10, 12, 14 or 16 bits");
-    const size_t row_bytes = bits ? row_stride : (size_t)e->geom.width * sizeof(uint16_t);
+    row_bytes = bits ? row_stride : (size_t)e->geom.width * sizeof(uint16_t);
     if (bits && (row_stride < ((size_t)e->geom.width * bits + 7) / 8 || row_stride > 0xffffffffu))
         return api_fail(RPF_ERR_INVALID_ARGUMENT, "row_stride shorter than a packed row");
     HIP_TRY(hipSetDevice(s->proc->device));
@@ -420,10 +480,22 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return api_fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
     e->dev.flags = 0;
+    b = BandLaunch{e->proc, e->geom, e->dev, static_cast<const unsigned char*>(d_band), (uint32_t)row_stride, bits, order,
+                   make_raw_params(*raw), d_out, out_format};
+    return RPF_OK;
+}
+}  // namespace
+
+int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
+                      const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags)
+{
+    BandLaunch b;
+    size_t row_bytes = 0;
+    int rc = prepare_band_launch(s, e, d_band, row_stride, bits, order, raw, d_out, out_format, b, row_bytes);
+    if (rc) return rc;
     hipStream_t cur = (hipStream_t)stream;
     unsigned char* band = static_cast<unsigned char*>(d_band);
-    const BandLaunch b{e, band, (uint32_t)row_stride, bits, order, make_raw_params(*raw), d_out, out_format};
-    const uint32_t rows = e->geom.rows;
+    const uint32_t rows = b.geom.rows;
     const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
     const bool split = ((exchange && (flags & RPF_SHARD_OVERLAP)) || (flags & RPF_SHARD_FORCE_SPLIT)) &&
                        rows >= 4 * 2 * EDGE_PAIRS;
@@ -460,6 +532,83 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
     HIP_TRY(launch_part(b, PART_EDGES, s->side));  // the halo rows' reader: on the stream every exchange ahead runs on
     HIP_TRY(hipEventRecord(s->done, s->side));
     HIP_TRY(hipStreamWaitEvent(cur, s->done, 0));
+    return RPF_OK;
+}
+
+int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
+                            const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags)
+{
+    if (flags & ~(uint32_t)(RPF_SHARD_NO_EXCHANGE | RPF_SHARD_TIMED))
+        return api_fail(RPF_ERR_INVALID_ARGUMENT, "rpf_shard_develop_async takes RPF_SHARD_NO_EXCHANGE and RPF_SHARD_TIMED only");
+    BandLaunch b;
+    size_t row_bytes = 0;
+    const int rc = prepare_band_launch(s, e, d_band, row_stride, bits, order, raw, d_out, out_format, b, row_bytes);
+    if (rc) return rc;
+    for (auto& a : s->ahead)
+        if (a.pending && a.band == d_band)
+            return api_fail(RPF_ERR_INVALID_ARGUMENT, "this band has an exchange ahead: its step is rpf_shard_develop's");
+    const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
+    rpf_shard::Step* t = new (std::nothrow) rpf_shard::Step{b, row_bytes, b.geom.rows, exchange, (flags & RPF_SHARD_TIMED) != 0,
+                                                           (hipStream_t)stream};
+    if (!t) return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: out of host memory");
+    try {
+        std::lock_guard<std::mutex> lock(s->mu);
+        s->work.push_back(rpf_shard::Work{nullptr, t});
+        ++s->in_flight;
+        if (!s->worker.joinable()) s->worker = std::thread(exchange_worker, s);
+    } catch (...) {
+        std::lock_guard<std::mutex> lock(s->mu);
+        if (!s->work.empty() && s->work.back().step == t) { s->work.pop_back(); --s->in_flight; }
+        delete t;
+        return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: could not start the shard's thread");
+    }
+    s->launch_i = -1;
+    s->cv.notify_all();
+    return RPF_OK;
+}
+
+int rpf_shard_flush(rpf_shard* s)
+{
+    if (!s) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null shard");
+    std::unique_lock<std::mutex> lock(s->mu);
+    s->cv.wait(lock, [&] { return s->in_flight == 0; });
+    if (s->async_rc) {
+        const int rc = s->async_rc;
+        const std::string msg = s->async_error;
+        s->async_rc = 0;
+        s->async_error.clear();
+        lock.unlock();
+        return api_fail(rc, msg);
+    }
+    return RPF_OK;
+}
+
+int rpf_shard_timing(rpf_shard* s, uint32_t* launches, double* total_ms)
+{
+    if (!s || !launches || !total_ms) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = rpf_shard_flush(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->proc->device));
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        pairs.swap(s->timing);
+    }
+    *launches = 0;
+    *total_ms = 0.0;
+    hipError_t first = hipSuccess;
+    for (auto& pr : pairs) {
+        float ms = 0.0f;
+        hipError_t he = hipEventSynchronize(pr.second);
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, pr.first, pr.second);
+        if (he == hipSuccess) { ++*launches; *total_ms += ms; }
+        else if (first == hipSuccess) first = he;
+    }
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        for (auto& pr : pairs) s->timing_free.push_back(pr);
+    }
+    if (first != hipSuccess) return api_hip_fail(first, "hipEventElapsedTime(timed launch)");
     return RPF_OK;
 }
 

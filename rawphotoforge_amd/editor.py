@@ -462,6 +462,25 @@ class Shard:
         _check(N.lib().rpf_shard_develop(self._h, editor._h, C.c_void_p(d_band_ptr), stride, bits, order, C.byref(rp),
                                          C.c_void_p(d_out_ptr), out_format, C.c_void_p(stream), flags))
 
+    def develop_async(self, editor: "PhotoEditor", d_band_ptr: int, raw, d_out_ptr: int, out_format: int = N.OUT_RGBA_F32,
+                      stream: int = 0, flags: int = 0, packed=None) -> None:
+        """The same step handed to the shard's own thread (rpf_shard_develop_async): returns at once; flags
+        SHARD_NO_EXCHANGE / SHARD_TIMED.  Two shards, two streams, frames alternating: see include/rpf.h."""
+        rp = raw if isinstance(raw, N.RawParams) else raw.to_c()
+        bits, stride, order = packed if packed else (0, 0, 0)
+        _check(N.lib().rpf_shard_develop_async(self._h, editor._h, C.c_void_p(d_band_ptr), stride, bits, order, C.byref(rp),
+                                               C.c_void_p(d_out_ptr), out_format, C.c_void_p(stream), flags))
+
+    def flush(self) -> None:
+        """Block until every step handed to develop_async is enqueued on its stream; raises its first failure."""
+        _check(N.lib().rpf_shard_flush(self._h))
+
+    def timing(self):
+        """(number, summed milliseconds) of the SHARD_TIMED launches since the last call (waits for them)."""
+        n, ms = C.c_uint32(), C.c_double()
+        _check(N.lib().rpf_shard_timing(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             N.lib().rpf_shard_destroy(self._h)

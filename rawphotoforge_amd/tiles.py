@@ -262,6 +262,16 @@ class ShardedDeveloper:
         row_bytes = self.packed[1] if self.packed else self.w * 2
         self.shard.exchange_ahead(band.data_ptr(), row_bytes, self.rows, stream, after_develop)
 
+    def step_async(self, band, out, out_format=0, exchange=True, stream=None, timed=False):
+        """The step handed to the shard's own thread (rpf_shard_develop_async); `stream`: a raw stream handle (default: the
+        current torch stream).  Call shard.flush() before synchronising the stream."""
+        from . import _native as N
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        self.shard.develop_async(self.ed, band.data_ptr(), self.raw, out.data_ptr(), out_format, stream,
+                                 (0 if exchange else self._no_exchange) | (N.SHARD_TIMED if timed else 0), self.packed)
+
     def step(self, band, out, out_format=0, bytes_per_px=16, exchange=True, events=None, stream=None):
         """band: (rows + 4, W) 2-byte tensor with halo rows (packed: (rows + 4, row_stride) uint8); out: rows x W pixels.
         `events`: optional (start, end) CUDA events recorded on the launch stream around the WHOLE step (the interior

@@ -193,6 +193,53 @@ def test_exchange_one_frame_ahead_on_two_band_buffers(gpu, after_develop):
 
 
 @gpu_only
+def test_two_independent_step_pipelines(gpu):
+    """rpf_shard_develop_async: steps handed to the shards' own threads.  Two shards (two one-rank communicators, each rank
+    its own neighbour), two streams, two band buffers with DIFFERENT frames and garbage halos, frames alternating for ten
+    steps; then flush + synchronise: each output must be the oracle's for the frame of its pipeline, and the timed launches
+    must have been counted."""
+    torch = pytest.importorskip("torch")
+    w, rows = 520, 96
+    rp = util.raw_params()
+    spec = syn.PARAM_SETS["S"]
+    lanes = []
+    for seed in (31, 32):
+        br = util.bayer_uniform(rows, w, seed=seed)
+        frame = np.concatenate([br[:2], br, br[-2:]])
+        want = O.develop(frame, rp, [util.oracle_params(spec)], y0=2, rows=rows)
+        pad = np.full((rows + 4, w), 4000 + seed, np.uint16)
+        pad[2:-2] = br
+        shard = R.Shard(gpu, None, 0, 1)
+        shard.set_neighbours(0, 0)
+        lanes.append(dict(want=want, br=br, band=torch.from_numpy(pad.view(np.int16)).cuda(),
+                          out=torch.full((rows, w, 4), -7.0, dtype=torch.float32, device="cuda"), shard=shard,
+                          stream=torch.cuda.Stream(),
+                          dev=tiles.ShardedDeveloper(gpu, w, rows + 4, 2, rows, util.to_raw(rp), lambda e: syn.configure(e, spec),
+                                                     shard=shard)))
+    torch.cuda.synchronize()
+    for k in range(10):
+        ln = lanes[k & 1]
+        ln["dev"].step_async(ln["band"], ln["out"], stream=ln["stream"].cuda_stream, timed=(k % 2 == 0) or k == 9)
+    for ln in lanes:
+        ln["shard"].flush()
+    torch.cuda.synchronize()
+    for ln in lanes:
+        got = ln["band"].cpu().numpy().view(np.uint16)
+        assert np.array_equal(got[:2], ln["br"][:2]) and np.array_equal(got[-2:], ln["br"][-2:])
+        _exact(ln["out"].cpu().numpy(), ln["want"])
+    n0, ms0 = lanes[0]["shard"].timing()
+    n1, ms1 = lanes[1]["shard"].timing()
+    assert (n0, n1) == (5, 1) and ms0 > 0 and ms1 > 0
+    assert lanes[0]["shard"].timing() == (0, 0.0)          # counted once
+    # the split schedules are rpf_shard_develop's; a failure inside a handed-over step surfaces at flush
+    ln = lanes[0]
+    with pytest.raises(R.InvalidArgument):
+        ln["shard"].develop_async(ln["dev"].ed, ln["band"].data_ptr(), ln["dev"].raw, ln["out"].data_ptr(), flags=R.SHARD_OVERLAP)
+    for ln in lanes:
+        ln["shard"].close()
+
+
+@gpu_only
 def test_exchange_ahead_slots_and_destroy_with_exchanges_pending(gpu):
     """Four bands may be ahead at once, a fifth is refused; a shard destroyed while exchanges are pending lets its exchange
     thread enqueue them, drains the side stream and returns (the rank is its own neighbour, so every group completes)."""
@@ -278,6 +325,9 @@ def test_shard_entry_points_refuse_null_handles(hip_lib):
     assert lib.rpf_shard_set_neighbours(None, 0, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_exchange(None, None, 0, 0, None) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_exchange_ahead(None, None, 0, 0, None, 0) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_develop_async(None, None, None, 0, 0, 0, None, None, 0, None, 0) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_flush(None) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_timing(None, None, None) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_develop(None, None, None, 0, 0, 0, None, None, 0, None, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_info(None, None, None, None, None, None, 0) == N.ERR_INVALID_ARGUMENT
     lib.rpf_shard_destroy(None)   # a no-op, like free(NULL)
@@ -313,18 +363,20 @@ def test_bench_two_ranks_rehearsal_and_rccl_fallback(tmp_path):
 
 
 @gpu_only
-@pytest.mark.parametrize("schedule", ["ahead", "serial", "once"])
+@pytest.mark.parametrize("schedule", ["pingpong", "ahead", "serial", "once"])
 def test_bench_sharded_code_path_rehearsed_on_one_gpu(schedule):
     """The N > 1 branch of bench.py with the LIBRARY's communicator (what the driver's --gpus N run takes on a node),
-    rehearsed in one process: rank 4 of 8's band of THE frame, the rank its own neighbour.  The exchange-ahead schedule is
-    the default there: two band buffers, one exchange + one launch per step, one untimed step to drain."""
+    rehearsed in one process: rank 4 of 8's band of THE frame, the rank its own neighbour.  The default there is two
+    independent step pipelines (pingpong: two shards with a thread each, two streams, rpf_shard_develop_async); the
+    exchange-ahead schedule, exchange-then-launch and the editing-session mode are selectable."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--preheat", "5",
-           "--rehearse-ranks", "8"] + {"serial": ["--schedule", "serial"], "once": ["--halo", "once"], "ahead": []}[schedule]
+           "--rehearse-ranks", "8"] + {"serial": ["--schedule", "serial"], "once": ["--halo", "once"],
+                                       "ahead": ["--schedule", "ahead"], "pingpong": []}[schedule]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
