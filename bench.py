@@ -168,10 +168,15 @@ def main():
 
     # ---- who exchanges the halos at N > 1 -------------------------------------------------------------------------
     exchange_note, shard, shard_b = None, None, None
+    # the pingpong schedule's second communicator — only where it will be used: an idle communicator is not free
+    want_two = (args.schedule in ("auto", "pingpong") and not args.overlap and args.halo == "step"
+                and args.workload in ("develop", "develop_packed"))
     if rehearse:
-        shard, shard_b = R.Shard(gpu, None, 0, 1), R.Shard(gpu, None, 0, 1)   # (the second one: the pingpong schedule's)
+        shard = R.Shard(gpu, None, 0, 1)
         shard.set_neighbours(0, 0)
-        shard_b.set_neighbours(0, 0)
+        if want_two:
+            shard_b = R.Shard(gpu, None, 0, 1)
+            shard_b.set_neighbours(0, 0)
         exchange_note = ("REHEARSAL on one GPU: librpf_hip.so's ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd on a one-rank "
                          "communicator, the rank its own neighbour above and below (no xGMI hop in this figure)")
     elif sharded:
@@ -183,7 +188,8 @@ def main():
             ids = [None, "", None]   # two communicators: the pingpong schedule runs two independent step pipelines
             if rank == 0:
                 try:
-                    ids[0], ids[2] = R.Shard.unique_id(), R.Shard.unique_id()
+                    ids[0] = R.Shard.unique_id()
+                    ids[2] = R.Shard.unique_id() if want_two else None
                 except R.PhotoEditorError as ex:   # e.g. librccl cannot be loaded: the other ranks must hear of it
                     ids[0], ids[1] = None, str(ex)
             dist.broadcast_object_list(ids, src=0)
@@ -192,7 +198,8 @@ def main():
             else:
                 try:
                     shard = R.Shard(gpu, ids[0], rank, world)
-                    shard_b = R.Shard(gpu, ids[2], rank, world)
+                    if want_two:
+                        shard_b = R.Shard(gpu, ids[2], rank, world)
                 except R.PhotoEditorError as ex:   # every rank must agree on the path: gathered below
                     err = str(ex)
             oks = [None] * world
@@ -216,7 +223,7 @@ def main():
         schedule = "serial"
     lib_sched_ok = sharded and shard is not None and args.workload in ("develop", "develop_packed")
     if schedule == "auto":
-        schedule = "pingpong" if lib_sched_ok else "serial"
+        schedule = "pingpong" if (lib_sched_ok and shard_b is not None) else "serial"
     if schedule in ("ahead", "pingpong") and not lib_sched_ok:
         raise SystemExit(f"--schedule {schedule} needs the library's communicator (N > 1, --exchange rccl) and a fused develop workload")
     args.overlap = schedule == "overlap"
@@ -349,7 +356,7 @@ def main():
         pp_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0))
 
     def drain():   # pingpong: the shards' threads have enqueued everything handed to them; then the device
-        if schedule == "pingpong":
+        if schedule == "pingpong":   # (flush FIRST: a device-wide synchronise while the threads are still enqueuing is slow)
             shard.flush()
             shard_b.flush()
         torch.cuda.synchronize()
