@@ -278,7 +278,8 @@ int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_edito
  * per process and GPU: with lens_distortion = 0 a pixel needs its own sample and a 5x5 CFA neighbourhood, so a band needs
  * the two Bayer rows above and below it from its neighbours and nothing else.  An rpf_shard is one rank's end of that
  * exchange: an RCCL communicator (librccl is loaded at rpf_shard_create, not linked: a single-GPU host never touches it),
- * a side stream and two events.  One call per frame, rpf_shard_develop, enqueues the whole step and returns.  By default
+ * a side stream, a few events and (from the first rpf_shard_exchange_ahead / rpf_shard_develop_async on) a thread of its
+ * own that makes the RCCL calls.  One call per frame, rpf_shard_develop, enqueues the whole step and returns.  By default
  * that is, on `stream`: ncclGroupStart, ncclSend / ncclRecv of the 2-row halos with the ranks above and below, ncclGroupEnd,
  * then the fused kernel over the band.  With RPF_SHARD_OVERLAP the exchange (xGMI latency, not bandwidth: 2 x 2 x width
  * bytes per direction) hides behind the rows that need no halo:

@@ -86,3 +86,17 @@ def test_header_is_plain_c_and_a_c_host_drives_the_device_free_part(tmp_path):
 def test_c_host_develops_a_frame(tmp_path):
     out = subprocess.run([_build_c_host(tmp_path), "gpu"], capture_output=True, text=True)
     assert out.returncode == 0 and "host_check ok" in out.stdout, out.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_runs_two_sharded_step_pipelines(tmp_path):
+    """tests/c_host/shard_check.c: rpf_shard_create x 2, rpf_shard_develop_async on two streams, flush, timing — from C, with
+    HIP's C API for buffers and streams, checked against rpf_dev_develop on self-exchanged halos."""
+    from rawphotoforge_amd import build as b
+    exe = str(tmp_path / "shard_check")
+    libdir = os.path.dirname(b.LIB)
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(util.ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(util.ROOT, "tests", "c_host", "shard_check.c"), "-o", exe, "-L", libdir, "-lrpf_hip",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "shard_check ok" in out.stdout, out.stderr + out.stdout
