@@ -220,10 +220,11 @@ int enqueue_exchange(rpf_shard* s, unsigned char* band, size_t row_bytes, uint32
 }
 
 hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream, hipEvent_t stop_event = nullptr,
-                       hipEvent_t start_event = nullptr)
+                       hipEvent_t start_event = nullptr, int reserve_cus = 0)
 {
     LaunchCfg cfg = cfg_of(b.proc);
     cfg.part = part;
+    if (reserve_cus > 0 && cfg.num_cus > 4 * reserve_cus) cfg.num_cus -= reserve_cus;
     cfg.stop_event = stop_event;
     cfg.start_event = start_event;
     if (b.bits)
@@ -284,7 +285,11 @@ int run_step(rpf_shard* s, const rpf_shard::Step& t)
         HIP_TRY(hipEventCreate(&ev.first));
         HIP_TRY(hipEventCreate(&ev.second));
     }
-    HIP_TRY(launch_part(t.b, PART_ALL, t.stream, ev.second, ev.first));
+    // A step that exchanges is one of two pipelines: its launch leaves a CU per XCD to the OTHER pipeline's exchange, which
+    // starts while this kernel runs — RCCL's workgroup needs a CU of its own (the fused kernel's persistent workgroups
+    // fill theirs), and a persistent workgroup that has to wait for that CU makes its whole launch late.
+    static const int reserve = getenv("RPF_SHARD_ASYNC_RESERVE") ? atoi(getenv("RPF_SHARD_ASYNC_RESERVE")) : 8;
+    HIP_TRY(launch_part(t.b, PART_ALL, t.stream, ev.second, ev.first, t.exchange ? reserve : 0));
     if (t.timed) {
         std::lock_guard<std::mutex> lock(s->mu);
         s->timing.push_back(ev);
