@@ -101,6 +101,16 @@ int api_sync_edit_state(rpf_editor* e) { return sync_edit_state(e); }
 static int sync_edit_state_impl(rpf_editor* e)
 {
     const uint32_t n = (uint32_t)e->state.masks.size();
+    // The vignette's falloff depends on the pixel's position alone: one map per editor (4 B per pixel), computed when the
+    // slider first leaves 0 (active shader flavour: the Godot-legacy falloff is another function and is evaluated in
+    // place), read by the kernels instead of a square root, a quotient and a pow(t, 1.5) per pixel.
+    if (e->state.masks[0].params.vignette != 0 && e->flavour == RPF_FLAVOUR_ACTIVE && !e->d_vign_falloff && npix_of(e) > 0 &&
+        npix_of(e) * sizeof(float) <= 0xffffffffull) {
+        HIP_TRY(hipMalloc((void**)&e->d_vign_falloff, npix_of(e) * sizeof(float)));
+        HIP_TRY(launch_vignette_falloff(e->geom, e->d_vign_falloff, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));  // rpf_dev_* callers launch on their own streams
+        e->dev.vign_falloff = e->d_vign_falloff;   // (vign_strength != 0 was or is being uploaded with this very state)
+    }
     if (e->uploaded_params == e->state.params_version && e->uploaded_masks == e->state.masks_version) return ok();
     const bool masks_changed = e->uploaded_masks != e->state.masks_version;
     bool synced = false;  // kernels launched earlier (on this editor's stream or a caller's) may still read the old tables
@@ -163,6 +173,7 @@ static int sync_edit_state_impl(rpf_editor* e)
     const rpf_gpu_edit_parameters g0 = convert_params(e->state.masks[0].params);
     e->dev.vign_strength = (-g0.vignette / 100.0f) * 2.0f;     // wgsl:167 (main mask only, :276)
     e->dev.lens_strength = -0.5f * (g0.lens_distortion / 100.0f);  // wgsl:110 (main mask only, :273)
+    e->dev.vign_falloff = e->dev.vign_strength != 0.0f ? e->d_vign_falloff : nullptr;
     e->dev.num_masks = n;
     e->dev.bright = e->d_bright;
     e->dev.hsl = e->d_hsl;
@@ -347,7 +358,8 @@ void rpf_editor_destroy(rpf_editor* e)
     if (!e) return;
     if (e->proc && hipSetDevice(e->proc->device) == hipSuccess) {
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits};
+        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits,
+                        e->d_vign_falloff};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         if (e->stream) (void)hipStreamDestroy(e->stream);

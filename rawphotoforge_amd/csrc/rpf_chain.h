@@ -110,14 +110,24 @@ RPF_HD float vignette_axis2(int i, float n)
     const float c = ((float)i / n - 0.5f) * 1.5f;
     return c * c;
 }
-RPF_HD float vignette_from_axes(float vign_strength, float cx2, float cy2)
+// The part that depends on the pixel's position alone (a kernel may read it from a map computed once per tile:
+// DeviceEdit::vign_falloff) ...
+RPF_HD float vignette_falloff_from_axes(float cx2, float cy2)
 {
     const float dist = sqrt_cr(cx2 + cy2);
     // (dist - 0.25) / 0.75 by Markstein's sequence: equal to the IEEE quotient (every binary32 in [-0.25, 2] checked,
     // tests/test_math_exhaustive.py)
     const float t = div_by_const(dist - 0.25f, 0.75f, (float)(1.0 / 0.75));
-    const float falloff = pow_1p5(clampf(t, 0.0f, 1.0f));
+    return pow_1p5(clampf(t, 0.0f, 1.0f));
+}
+// ... and the part that depends on the slider.
+RPF_HD float vignette_gain_from_falloff(float vign_strength, float falloff)
+{
     return clampf(1.0f - (vign_strength * falloff), 0.0f, 4.0f);
+}
+RPF_HD float vignette_from_axes(float vign_strength, float cx2, float cy2)
+{
+    return vignette_gain_from_falloff(vign_strength, vignette_falloff_from_axes(cx2, cy2));
 }
 RPF_HD float vignette_gain(float vign_strength, int x, int y, float w, float h)
 {

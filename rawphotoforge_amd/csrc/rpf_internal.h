@@ -47,6 +47,7 @@ struct rpf_editor {
     ushort4* d_hsl = nullptr;
     uint8_t* d_masks = nullptr;       // user-mask planes as uploaded (u8, binarised)
     uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
+    float* d_vign_falloff = nullptr;  // rows x width: the vignette's falloff per pixel, built when the slider first leaves 0
     uint32_t lut_capacity = 0;    // masks worth of LUT storage
     uint32_t mask_capacity = 0;   // user-mask planes allocated
     uint64_t uploaded_params = 0, uploaded_masks = 0;

@@ -677,15 +677,15 @@ __device__ __forceinline__ HpRow hp_row_taps(float a, float b, float ha, float h
 template <int MODE, bool LDS_LUT, int OUTFMT, bool VIGN>
 __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (&b)[2], int row, const int (&col)[2],
                                           int colF, const TileGeom& g, const DeviceEdit& ed, const DevLuts<LDS_LUT>& luts,
-                                          const LdsTabs& T, void* out, const float (&vcx2)[2], float vcy2, uint32_t lds_mp,
+                                          const LdsTabs& T, void* out, const float (&fall)[2], uint32_t lds_mp,
                                           uint32_t dead_lo, uint32_t dead_hi, const uint32_t (&alpha)[2], const MaskParams* mainv)
 {
     const int W = (int)g.width, rows = (int)g.rows;
     // wave-uniform: the virtual rows above / below a band, and the rows a PART_EDGES launch leaves to the interior's
     const bool row_live = row >= 0 && row < rows && !((uint32_t)row >= dead_lo && (uint32_t)row < dead_hi);
-    if (VIGN) {  // wgsl:166-178, global coordinates
+    if (VIGN) {  // wgsl:166-178; the falloff of the two pixels comes from the tile's map (DeviceEdit::vign_falloff)
         for (int k = 0; k < 2; ++k) {
-            const float gain = vignette_from_axes(ed.vign_strength, vcx2[k], vcy2);
+            const float gain = vignette_gain_from_falloff(ed.vign_strength, fall[k]);
             r[k] *= gain; gg[k] *= gain; b[k] *= gain;
         }
     }
@@ -734,6 +734,9 @@ void k_hp(const StreamArgs a)
     const LdsTabs tabs(0u, T, a.ed.mp[0], true);
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
+    // the tile's vignette falloff map: rows x W binary32 (run_hp checks that it exists and is shorter than 4 GiB)
+    const __amdgpu_buffer_rsrc_t fall_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.ed.vign_falloff), 0, VIGN ? (int)(a.g.rows * a.g.width * 4u) : 0, RPF_BUFFER_RSRC_FLAGS);
 
     const int lane = tid & 63;
     const int W = (int)a.g.width, H = (int)a.g.height;
@@ -816,12 +819,19 @@ void k_hp(const StreamArgs a)
         auto taps = [&](const Raw4& q, int odd) {
             return hp_row_taps(norm(q.a, 2 * odd), norm(q.b, 2 * odd + 1), norm(q.ha, 2 * odd), norm(q.hb, 2 * odd + 1));
         };
-        float vcx2[2] = {0.0f, 0.0f}, vcy2_lane = 0.0f;
-        if (VIGN) {  // squared coordinates of the two columns once per item; lane j: of the item's output row j
-            vcx2[0] = vignette_axis2(xa, (float)W);
-            vcx2[1] = vignette_axis2(xa + 1, (float)W);
-            vcy2_lane = vignette_axis2(y0 + rbase + 2 + lane, (float)H);
-        }
+        // Vignette: the falloff of this lane's two pixels of a row, from the tile's map (DeviceEdit::vign_falloff), loaded
+        // one step ahead like the CFA rows.  A virtual row above / below the band reads the nearest real one (not stored).
+        struct Fall { float a, b; };
+        auto load_fall = [&](int row) {
+            Fall f{0.0f, 0.0f};
+            if (VIGN) {
+                const int rc = row < 0 ? 0 : (row > rows - 1 ? rows - 1 : row);
+                const uint32_t so = (uint32_t)rc * (uint32_t)W * 4u;
+                f.a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fall_rsrc, goffa * 2u, so, 0));
+                f.b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fall_rsrc, goffb * 2u, so, 0));
+            }
+            return f;
+        };
 
         float w0a, w0b;
         {
@@ -831,17 +841,16 @@ void k_hp(const StreamArgs a)
         HpRow t1 = taps(load_row(1), 1), t2 = taps(load_row(2), 0), t3 = taps(load_row(3), 1);
         Raw4 n4 = load_row(4), n5 = load_row(5);
 
+        Fall nf0 = load_fall(2 * pair0 - bp), nf1 = load_fall(2 * pair0 - bp + 1);
         for (int p = 0; p < npairs; ++p) {  // wave-uniform
             const HpRow t4 = taps(n4, 0), t5 = taps(n5, 1);
-            if (p + 1 < npairs) {  // prefetch the next step's two rows
+            const int row = 2 * (pair0 + p) - bp;
+            const float fall0[2] = {nf0.a, nf0.b}, fall1[2] = {nf1.a, nf1.b};
+            if (p + 1 < npairs) {  // prefetch the next step's two rows (and their falloff)
                 n4 = load_row(2 * p + 6);
                 n5 = load_row(2 * p + 7);
-            }
-            const int row = 2 * (pair0 + p) - bp;
-            float vcy2[2] = {0.0f, 0.0f};
-            if (VIGN) {
-                vcy2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p));
-                vcy2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vcy2_lane), 2 * p + 1));
+                nf0 = load_fall(row + 2);
+                nf1 = load_fall(row + 3);
             }
             float r[2], gg[2], b[2];
             {   // row 0 of the step (window position 2): a = R site, b = G site on the R row
@@ -854,7 +863,7 @@ void k_hp(const StreamArgs a)
                 const float vert = mhc_axis(t2.vb, s1b, db, vvb, t2.p2b);
                 cam_to_linear(camv, t2.va, cross, diag, r[0], gg[0], b[0]);
                 cam_to_linear(camv, horiz, t2.vb, vert, r[1], gg[1], b[1]);
-                hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[0],
+                hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, fall0,
                                                        MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha, &mainv);
             }
             {   // row 1 (window position 3): a = G site on the B row, b = B site
@@ -867,7 +876,7 @@ void k_hp(const StreamArgs a)
                 const float diag = mhc_diag(t3.vb, db, vvb, t3.p2b);
                 cam_to_linear(camv, vert, t3.va, horiz, r[0], gg[0], b[0]);
                 cam_to_linear(camv, diag, cross, t3.vb, r[1], gg[1], b[1]);
-                hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row + 1, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, vcx2, vcy2[1],
+                hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row + 1, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, fall1,
                                                        MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha, &mainv);
             }
             // slide the window down two rows
@@ -1002,7 +1011,8 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
     const uint32_t stride = gridDim.x * NT * 2;
-    const bool coords = LENS || a.ed.vign_strength != 0.0f;  // only these two stages look at the pixel position
+    // only these two stages look at the pixel position (the vignette not when its falloff comes from the map)
+    const bool coords = LENS || (a.ed.vign_strength != 0.0f && ((a.ed.flags & EF_LEGACY_VIGNETTE) || !a.ed.vign_falloff));
     // One iteration of a workgroup = 2 * NT consecutive pixels starting at `base` (wave-uniform).  Input and output
     // of the iteration are addressed through buffer descriptors of exactly that span, built in scalar registers: a
     // thread's byte offsets inside the span never change, and pixels past the end of the image fall outside the
@@ -1013,12 +1023,23 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     typedef uint32_t v3u __attribute__((ext_vector_type(3)));
     constexpr uint32_t BPP = out_bpp<OUTFMT>();
     v3u nxt[2];
+    // the vignette's falloff of the pair's pixels, from the editor's map when there is one (active flavour; rpf_launch.h
+    // DeviceEdit::vign_falloff), fetched with the pixels
+    const float* fmap = (a.ed.vign_strength != 0.0f && !(a.ed.flags & EF_LEGACY_VIGNETTE)) ? a.ed.vign_falloff : nullptr;
+    float nfall[2] = {0.0f, 0.0f};
     auto span = [&](uint32_t base) { return base >= npix ? 0u : (npix - base < 2u * NT ? npix - base : 2u * NT); };
     auto fetch = [&](uint32_t base) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float4*>(a.in) + base, 0, (int)(span(base) * 16u), RPF_BUFFER_RSRC_FLAGS);
 #pragma unroll
         for (int k = 0; k < 2; ++k) nxt[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, ((uint32_t)k * NT + tid) * 16u, 0, 2);
+        if (fmap) {
+            const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(fmap) + base, 0, (int)(span(base) * 4u), RPF_BUFFER_RSRC_FLAGS);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                nfall[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fr, ((uint32_t)k * NT + tid) * 4u, 0, 0));
+        }
     };
     uint32_t base = blockIdx.x * NT * 2;
     if (!LENS && base < npix) fetch(base);
@@ -1049,6 +1070,8 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
             pix[k] = live[k] ? p : npix - 1;
             if (!LENS) { r[k] = bits2f(nxt[k].x); g[k] = bits2f(nxt[k].y); b[k] = bits2f(nxt[k].z); }
         }
+        float fall[2] = {nfall[0], nfall[1]};
+        if (LENS && fmap) { fall[0] = fmap[pix[0]]; fall[1] = fmap[pix[1]]; }
         if (!LENS) fetch(base + stride);  // past the end of the image the span is empty: zeros that nobody uses
         const bool decode = (a.ed.flags & EF_DECODE_INPUT) != 0;  // Godot-legacy :281-283: the stored image is sRGB-encoded
         auto decode_px = [&](int k) {
@@ -1065,7 +1088,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
                 if (LENS)  // wgsl:123-163; a.in is the whole frame
                     lens_sample(TexFetch{a.in, W}, W, H, x, gy, a.ed.lens_strength, r[k], g[k], b[k]);
                 if (decode) decode_px(k);
-                if (a.ed.vign_strength != 0.0f) {
+                if (a.ed.vign_strength != 0.0f && !fmap) {
                     const float gain = (a.ed.flags & EF_LEGACY_VIGNETTE)
                                            ? vignette_gain_legacy(a.ed.vign_strength, x, gy, (float)W, (float)H)
                                            : vignette_gain(a.ed.vign_strength, x, gy, (float)W, (float)H);
@@ -1075,6 +1098,13 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         } else if (decode) {
             decode_px(0);
             decode_px(1);
+        }
+        if (fmap) {  // (after the lens resample and the legacy decode, where the chain has it)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float gain = vignette_gain_from_falloff(a.ed.vign_strength, fall[k]);
+                r[k] *= gain; g[k] *= gain; b[k] *= gain;
+            }
         }
         if (!SINGLE && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
@@ -1408,6 +1438,7 @@ static hipError_t interior_of(const TileGeom& g, const DeviceEdit& ed, int out_f
     edi = ed;
     skip_px = (size_t)first * g.width;
     if (ed.mask_bits) edi.mask_bits = ed.mask_bits + skip_px;
+    if (ed.vign_falloff) edi.vign_falloff = ed.vign_falloff + skip_px;
     return hipSuccess;
 }
 
@@ -1543,6 +1574,8 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
     const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
                        (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
     const bool vign = ed->vign_strength != 0.0f;
+    // k_hp reads the vignette's falloff from the tile's map (the API layer builds it when the slider leaves 0)
+    if (vign && (!ed->vign_falloff || (uint64_t)g.rows * g.width * 4u > 0xffffffffull)) return hipErrorInvalidValue;
     auto kernel = vign ? k_hp<NT, MODE, LDS_LUT, OUTFMT, true> : k_hp<NT, MODE, LDS_LUT, OUTFMT, false>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
@@ -1886,6 +1919,27 @@ hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t wi
         else hipLaunchKernelGGL((k_unpack<16, false>), dim3(grid), dim3(256), 0, s, d_packed, row_stride, width, rows, d_out, gpr);
         break;
     default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// The vignette's falloff of every pixel of a tile (DeviceEdit::vign_falloff), global coordinates (wgsl:169).
+__global__ __launch_bounds__(256) void k_vign_falloff(TileGeom g, float* map)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, r = blockIdx.y;
+    if (x >= g.width) return;
+    map[(size_t)r * g.width + x] = vignette_falloff_from_axes(vignette_axis2((int)x, (float)g.width),
+                                                             vignette_axis2((int)(g.y0 + r), (float)g.height));
+}
+
+hipError_t launch_vignette_falloff(const TileGeom& g, float* d_map, hipStream_t s)
+{
+    if (!d_map || g.width == 0 || g.rows == 0 || g.rows > 65535u * 16u) return hipErrorInvalidValue;
+    // (grid.y is limited to 65535: taller tiles in slabs)
+    for (uint32_t r0 = 0; r0 < g.rows; r0 += 65535u) {
+        const uint32_t nr = g.rows - r0 < 65535u ? g.rows - r0 : 65535u;
+        const TileGeom slab{g.width, g.height, g.y0 + r0, nr};
+        hipLaunchKernelGGL(k_vign_falloff, dim3((g.width + 255u) / 256u, nr), dim3(256), 0, s, slab, d_map + (size_t)r0 * g.width);
     }
     return hipGetLastError();
 }

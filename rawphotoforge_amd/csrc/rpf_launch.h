@@ -20,6 +20,11 @@ struct DeviceEdit {
     const HueBound* hue_bounds;  // 65536 boundary directions of the hue index (rpf_math.h hue_index)
     const HueBoundCs* hue_cs;    // the same boundaries with cos / sin of the hue angles attached (HUE_DIRECT launches)
     float vign_strength;         // (-vignette / 100) * 2, 0 = off       wgsl:167
+    // rows x width binary32: the vignette's falloff at every pixel of the tile (vignette_falloff_from_axes: a correctly
+    // rounded square root, quotient and pow(t, 1.5) per pixel that depend on the pixel's position alone), computed once
+    // per editor when the slider first leaves 0 (launch_vignette_falloff).  k_hp reads it (4 B per pixel instead of ~40
+    // instructions); the other kernels evaluate the falloff in place.  Null while vign_strength == 0.
+    const float* vign_falloff;
     float lens_strength;         // -0.5 * (lens_distortion / 100), 0 = off   wgsl:110
     // Godot-legacy shader flavour (k_apply only): EF_* bits, and the c = 2.4 table when EF_DECODE_INPUT is set
     uint32_t flags;
@@ -52,6 +57,8 @@ struct LaunchCfg {
 };
 
 // d_cfa: (rows + 4) x width u16, row r = frame row y0 - 2 + r
+// d_map[r * width + x] = vignette_falloff_from_axes at frame pixel (x, y0 + r): DeviceEdit::vign_falloff of that tile
+hipError_t launch_vignette_falloff(const TileGeom& g, float* d_map, hipStream_t s);
 hipError_t launch_demosaic(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                            float* d_rgba, hipStream_t s);
 hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,

@@ -124,6 +124,11 @@ def test_gpu_legacy_bayer_editor_and_device_layer(gpu):
     lin = O.demosaic(cfa, rp)                       # the frame is linear already: only the vignette changes
     want = O.apply(lin, [p], legacy="linear")
     _exact(ed.to_flat_vec_rgba(), want)
+    # back to the active shader with unchanged edit state: the fused kernel reads the vignette's falloff from the editor's
+    # map, which has to appear although no setter ran in between
+    ed.set_shader_flavour(R.FLAVOUR_ACTIVE)
+    ed.apply_adjustments()
+    _exact(ed.to_flat_vec_rgba(), O.develop(cfa, rp, [p]))
     # device-pointer layer: the fused kernel is the active shader only; demosaic + apply serves the legacy one
     t = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
     util.configure_editor(t, p)
