@@ -240,6 +240,50 @@ def test_two_independent_step_pipelines(gpu):
 
 
 @gpu_only
+def test_async_pipelines_under_load(gpu):
+    """1500 steps through two pipelines with flushes, timing reads and an edit-state change in between (after a flush, as
+    include/rpf.h asks): no step lost, the outputs follow the edit state, the timed launches add up."""
+    torch = pytest.importorskip("torch")
+    w, rows = 264, 48
+    rp = util.raw_params()
+    specs = [syn.PARAM_SETS["D"], syn.PARAM_SETS["S"]]
+    lanes = []
+    for i in range(2):
+        br = util.bayer_uniform(rows, w, seed=70 + i)
+        frame = np.concatenate([br[:2], br, br[-2:]])
+        pad = np.zeros((rows + 4, w), np.uint16)
+        pad[2:-2] = br
+        shard = R.Shard(gpu, None, 0, 1)
+        shard.set_neighbours(0, 0)
+        lanes.append(dict(frame=frame, band=torch.from_numpy(pad.view(np.int16)).cuda(),
+                          out=torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda"), shard=shard,
+                          stream=torch.cuda.Stream(priority=-i),
+                          dev=tiles.ShardedDeveloper(gpu, w, rows + 4, 2, rows, util.to_raw(rp), lambda e: syn.configure(e, specs[0]),
+                                                     shard=shard)))
+    timed = [0, 0]
+    for phase, spec in enumerate(specs):
+        if phase:   # everything handed over has been enqueued and has run: now the edit state may change
+            for ln in lanes:
+                syn.configure(ln["dev"].ed, spec)
+        for k in range(750):
+            ln = lanes[k & 1]
+            t = k % 7 == 0
+            timed[k & 1] += t
+            ln["dev"].step_async(ln["band"], ln["out"], stream=ln["stream"].cuda_stream, timed=t)
+            if k % 200 == 199:
+                lanes[0]["shard"].flush()
+        for ln in lanes:
+            ln["shard"].flush()
+        torch.cuda.synchronize()
+        for ln in lanes:
+            _exact(ln["out"].cpu().numpy(), O.develop(ln["frame"], rp, [util.oracle_params(spec)], y0=2, rows=rows))
+    got = [ln["shard"].timing() for ln in lanes]
+    assert [g[0] for g in got] == timed and all(g[1] > 0 for g in got)
+    for ln in lanes:
+        ln["shard"].close()
+
+
+@gpu_only
 def test_exchange_ahead_slots_and_destroy_with_exchanges_pending(gpu):
     """Four bands may be ahead at once, a fifth is refused; a shard destroyed while exchanges are pending lets its exchange
     thread enqueue them, drains the side stream and returns (the rank is its own neighbour, so every group completes)."""
