@@ -58,6 +58,58 @@ __global__ __launch_bounds__(256) void k_gather(const unsigned char* table, uint
     out[blockIdx.x * 256u + threadIdx.x] = acc;
 }
 
+// The random 16-byte gather again through a buffer descriptor, with the load's cache-policy bits (gfx940+: aux bit 0 =
+// sc0, bit 1 = nt, bit 4 = sc1) as a template parameter: does any policy make a missing line cheaper than a 128-byte fill?
+template <int AUX>
+__global__ __launch_bounds__(256) void k_gather_policy(const unsigned char* table, uint32_t nentries, uint32_t* out)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(table), 0, (int)(nentries * 16u), 0x00020000);
+    uint32_t rnd = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    uint32_t acc = 0;
+    for (int it = 0; it < ITERS; ++it) {
+        uint32_t idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rnd = rnd * 1664525u + 1013904223u;
+            idx[u] = (rnd >> 8) % nentries;
+        }
+        v4u v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, idx[u] * 16u, 0, AUX);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    out[blockIdx.x * 256u + threadIdx.x] = acc;
+}
+
+template <int AUX>
+static void run_policy(const char* what)
+{
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount, blocks = cus * 5;
+    const size_t table_bytes = 2048 * 1024;
+    unsigned char* tab; uint32_t* out;
+    (void)hipMalloc(&tab, table_bytes);
+    (void)hipMemset(tab, 1, table_bytes);
+    (void)hipMalloc(&out, sizeof(uint32_t) * blocks * 256);
+    const uint32_t n = (uint32_t)(table_bytes / 16);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_gather_policy<AUX>), dim3(blocks), dim3(256), 0, 0, tab, n, out);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_gather_policy<AUX>), dim3(blocks), dim3(256), 0, 0, tab, n, out);
+    (void)hipEventRecord(e1, 0);
+    (void)hipDeviceSynchronize();
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double ns = ms * 1e6 / (20.0 * ITERS * 4.0);
+    printf("random 16 B/lane, 2048 KiB table, buffer load, policy %-12s: %7.2f ns per gather per CU = %5.2f distinct lines / ns / CU\n",
+           what, ns, 62.0 / ns);
+    (void)hipFree(tab); (void)hipFree(out);
+}
+
 template <int ESZ, int PATTERN>
 static void run(const char* what, size_t table_bytes, double lines_per_gather)
 {
@@ -86,8 +138,19 @@ static void run(const char* what, size_t table_bytes, double lines_per_gather)
     (void)hipFree(tab); (void)hipFree(out);
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    if (argc > 1 && argv[1][0] == 'p') {   // gather_probe policy
+        run_policy<0>("default");
+        run_policy<1>("sc0");
+        run_policy<2>("nt");
+        run_policy<3>("sc0 nt");
+        run_policy<16>("sc1");
+        run_policy<17>("sc0 sc1");
+        run_policy<18>("sc1 nt");
+        run_policy<19>("sc0 sc1 nt");
+        return 0;
+    }
     for (size_t kb : {16, 128, 1024, 2048}) {
         run<16, 0>("random", kb * 1024, kb >= 128 ? 62.0 : 0);
         run<8, 0>("random", kb * 1024, kb >= 128 ? 62.0 : 0);
