@@ -170,6 +170,35 @@ static int sync_edit_state_impl(rpf_editor* e)
             for (int c = RPF_CURVE_HUE; c <= RPF_CURVE_LIGHTNESS; ++c) up.v[c] = p.curve_ver[c];
         }
     }
+    // One mask whose hue / saturation / lightness curves are not all trivial: fold them into the editor's fused hue table
+    // (one gather per pixel instead of two and sincos_hue); rebuilt only when what it is made of changed.
+    {
+        const MaskParams& P0 = e->dev.mp[0];
+        const EditParameters& p0 = e->state.masks[0].params;
+        const bool trivial = (P0.flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) == (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
+        bool use = n == 1 && !trivial && e->d_hsl;
+        if (use) {
+            const bool same = e->hue_fused_valid && e->hue_fused_flags == P0.flags && e->hue_fused_gains[0] == P0.sat_gain &&
+                              e->hue_fused_gains[1] == P0.light_gain && e->hue_fused_stamp[0] == p0.curve_ver[RPF_CURVE_HUE] &&
+                              e->hue_fused_stamp[1] == p0.curve_ver[RPF_CURVE_SATURATION] &&
+                              e->hue_fused_stamp[2] == p0.curve_ver[RPF_CURVE_LIGHTNESS];
+            if (!same) {
+                if ((rc = quiesce())) return rc;
+                if (!e->d_hue_fused_alloc)
+                    HIP_TRY(hipMalloc(&e->d_hue_fused_alloc, sizeof(HueFusedData) + (size_t)RPF_CURVE_RESOLUTION * sizeof(HueFused)));
+                HueFused* t = reinterpret_cast<HueFused*>(static_cast<char*>(e->d_hue_fused_alloc) + sizeof(HueFusedData));
+                HIP_TRY(launch_build_hue_fused(e->proc->d_hue_bounds, e->d_hsl, P0, e->proc->d_tabs, t, e->stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));  // rpf_dev_* callers launch on their own streams
+                e->hue_fused_valid = true;
+                e->hue_fused_flags = P0.flags;
+                e->hue_fused_gains[0] = P0.sat_gain; e->hue_fused_gains[1] = P0.light_gain;
+                e->hue_fused_stamp[0] = p0.curve_ver[RPF_CURVE_HUE];
+                e->hue_fused_stamp[1] = p0.curve_ver[RPF_CURVE_SATURATION];
+                e->hue_fused_stamp[2] = p0.curve_ver[RPF_CURVE_LIGHTNESS];
+            }
+        }
+        e->dev.hue_fused = use ? reinterpret_cast<const HueFused*>(static_cast<char*>(e->d_hue_fused_alloc) + sizeof(HueFusedData)) : nullptr;
+    }
     const rpf_gpu_edit_parameters g0 = convert_params(e->state.masks[0].params);
     e->dev.vign_strength = (-g0.vignette / 100.0f) * 2.0f;     // wgsl:167 (main mask only, :276)
     e->dev.lens_strength = -0.5f * (g0.lens_distortion / 100.0f);  // wgsl:110 (main mask only, :273)
@@ -359,7 +388,7 @@ void rpf_editor_destroy(rpf_editor* e)
     if (e->proc && hipSetDevice(e->proc->device) == hipSuccess) {
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits,
-                        e->d_vign_falloff};
+                        e->d_vign_falloff, e->d_hue_fused_alloc};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -328,7 +328,7 @@ template <class Tabs> RPF_HD float chain_main_sat(const Tabs&, const MaskParams&
 template <class Tabs> RPF_HD float chain_main_light(const Tabs&, const MaskParams& P) { return P.light_gain; }
 
 // STATIC_FLAGS (>= 0): "main"'s flag word, known at compile time (the caller's promise that mp[0].flags equals it).
-template <int N, bool HUE_DIRECT = false, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
+template <int N, int HUE_MODE = 0, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
 RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],
                        const Params& mp, uint32_t num_masks, const Luts& luts, const Tabs& T)
 {
@@ -354,7 +354,10 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
     }
 
     // linear_srgb_to_oklch, wgsl:64-75.  The hue is only ever used as a curve index (hue_index, rpf_math.h).
-    float L[N], C[N], h[N], cs0[N], sn0[N];
+    // HUE_MODE: 0 = any masks and curves; 1 = HUE_DIRECT (see above); 2 = HUE_FUSED: one mask whose curves are folded
+    // into the hue table (rpf_math.h HueFused): index, cos / sin of the NEW hue and both gains from one gather
+    constexpr bool HUE_DIRECT = HUE_MODE == 1, HUE_FUSED = HUE_MODE == 2;
+    float L[N], C[N], h[N], cs0[N], sn0[N], sg0[N], lg0[N];
     uint32_t hu0[N];
     for (int n = 0; n < N; ++n) {
         const float l = RPF_F(0.4122214708) * r[n] + RPF_F(0.5363325363) * g[n] + RPF_F(0.0514459929) * b[n];
@@ -372,7 +375,10 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         // u32(h * 65535), h = atan2(b, a) / (2 pi) wrapped (wgsl:72-73, 320).  A is never -0 here: the cube roots are
         // >= +0, so its first product is +0 or positive and a round-to-nearest sum that cancels exactly is +0 —
         // hue_index's atan2(+-0, -0) argument cannot occur (NEG_ZERO_X = false).
-        if (HUE_DIRECT) {
+        sg0[n] = lg0[n] = 1.0f;
+        if constexpr (HUE_FUSED) {
+            hu0[n] = hue_index_fused<false>(Bq, A, luts.hue_fused(), cs0[n], sn0[n], sg0[n], lg0[n]);
+        } else if constexpr (HUE_DIRECT) {
             hu0[n] = hue_index_cs<false>(Bq, A, luts.hue_bounds_cs(), T.sc, cs0[n], sn0[n]);
         } else {
             hu0[n] = hue_index<false>(Bq, A, luts.hue_bounds());
@@ -400,7 +406,11 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
             L[n] = on ? L[n] * light_gain : L[n];
         }
     };
-    oklch_stage(0u, true);  // "main" is always active and replaces the hue by curve[k] / 65535
+    if constexpr (HUE_FUSED) {  // "main"'s curves came with the table entry: only the two products are left
+        for (int n = 0; n < N; ++n) { C[n] = C[n] * sg0[n]; L[n] = L[n] * lg0[n]; }
+    } else {
+        oklch_stage(0u, true);  // "main" is always active and replaces the hue by curve[k] / 65535
+    }
     for (uint32_t m = 1; m < num_masks; ++m)
         if ((any_active >> m) & 1u) oklch_stage(m, false);
 
@@ -408,7 +418,7 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
     // here is always k/65535 for the integer k the last active mask fetched ("main" is always active).
     for (int n = 0; n < N; ++n) {
         float cs = cs0[n], sn = sn0[n];
-        if (!HUE_DIRECT) sincos_hue(hue_k[n], T.sc, cs, sn);
+        if (!HUE_DIRECT && !HUE_FUSED) sincos_hue(hue_k[n], T.sc, cs, sn);
         const float oa = C[n] * cs, ob = C[n] * sn;
         const float l_ = RPF_F(1.0) * L[n] + RPF_F(0.3963377774) * oa + RPF_F(0.2158037573) * ob;
         const float m_ = RPF_F(1.0) * L[n] + RPF_F(-0.1055613458) * oa + RPF_F(-0.0638541728) * ob;

@@ -47,6 +47,13 @@ struct rpf_editor {
     ushort4* d_hsl = nullptr;
     uint8_t* d_masks = nullptr;       // user-mask planes as uploaded (u8, binarised)
     uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
+    // one mask with non-trivial hue / saturation / lightness curves: the fused hue table (allocation starts 16 bytes, one
+    // HueFusedData, before entry 0) and what it was built from
+    void* d_hue_fused_alloc = nullptr;
+    uint64_t hue_fused_stamp[3] = {~0ull, ~0ull, ~0ull};  // curve versions (hue, saturation, lightness) of "main"
+    uint32_t hue_fused_flags = 0;
+    float hue_fused_gains[2] = {0.0f, 0.0f};
+    bool hue_fused_valid = false;
     float* d_vign_falloff = nullptr;  // rows x width: the vignette's falloff per pixel, built when the slider first leaves 0
     uint32_t lut_capacity = 0;    // masks worth of LUT storage
     uint32_t mask_capacity = 0;   // user-mask planes allocated

@@ -141,8 +141,10 @@ struct DevLuts {
     const ushort4* g_hsl;
     const HueBound* g_hue_bounds;
     const HueBoundCs* g_hue_cs;
+    const HueFused* g_hue_fused;
     __device__ __forceinline__ const HueBound* hue_bounds() const { return g_hue_bounds; }
     __device__ __forceinline__ const HueBoundCs* hue_bounds_cs() const { return g_hue_cs; }
+    __device__ __forceinline__ const HueFused* hue_fused() const { return g_hue_fused; }
     __device__ __forceinline__ uint32_t brightness(uint32_t m, uint32_t i) const
     {
         if (LDS_LUT && m == 0) return lds_bright[i];
@@ -307,13 +309,13 @@ __device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (
                                           const MaskParams* mainv = nullptr)  // pin_main_params' copy (k_hp)
 {
     if (MODE == MODE_DEVELOP_1P) {
-        edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, ed.mp, 1u, luts, T);
+        edit_chain<2, 1, (int)MF_PRISTINE>(r, gg, b, active, ed.mp, 1u, luts, T);
     } else if (MODE == MODE_DEVELOP_1H) {
-        if (mainv) edit_chain<2, true>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
-        else edit_chain<2, true>(r, gg, b, active, ed.mp, 1u, luts, T);
-    } else if (MODE == MODE_DEVELOP_1) {
-        if (mainv) edit_chain<2>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
-        else edit_chain<2>(r, gg, b, active, ed.mp, 1u, luts, T);
+        if (mainv) edit_chain<2, 1>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
+        else edit_chain<2, 1>(r, gg, b, active, ed.mp, 1u, luts, T);
+    } else if (MODE == MODE_DEVELOP_1) {  // one mask, non-identity hue curve: its curves are folded into the hue table
+        if (mainv) edit_chain<2, 2>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
+        else edit_chain<2, 2>(r, gg, b, active, ed.mp, 1u, luts, T);
     } else if (MODE == MODE_DEVELOP_SEQ) {
         for (int k = 0; k < 2; ++k) {
             float r1[1] = {r[k]}, g1[1] = {gg[k]}, b1[1] = {b[k]};
@@ -322,9 +324,9 @@ __device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (
             r[k] = r1[0]; gg[k] = g1[0]; b[k] = b1[0];
         }
     } else if (MODE == MODE_DEVELOP_MPH) {
-        edit_chain<2, true, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
+        edit_chain<2, 1, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
     } else if (MODE == MODE_DEVELOP_MP) {
-        edit_chain<2, false, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
+        edit_chain<2, 0, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
     } else if (lds_mp != 0xffffffffu) {
         edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp, mainv}, ed.num_masks, luts, T);
     } else {
@@ -464,7 +466,7 @@ void k_stream(const StreamArgs a)
         if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
     const LdsTabs tabs(0u, T, a.ed.mp[0], false);
     // the u16 band as one buffer: (rows + 4) rows of W samples (run_stream checks that it is shorter than 4 GiB)
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -730,7 +732,7 @@ void k_hp(const StreamArgs a)
     stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();  // the only barrier of the kernel
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
     const LdsTabs tabs(0u, T, a.ed.mp[0], true);
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
     const int lx = tid & (TILE_W - 1);
     const int ly = 2 * (tid / TILE_W);
     const int lane = tid & 63;
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
 
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         const int tx0 = (int)(t % a.tiles_x) * TILE_W;
@@ -1006,7 +1008,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
     if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
     const LdsTabs tabs(0u, T, a.ed.mp[0], true);
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
@@ -1109,9 +1111,9 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         if (!SINGLE && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
         if (SINGLE == 3)
-            edit_chain<2, false, (int)MF_PRISTINE>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+            edit_chain<2, 0, (int)MF_PRISTINE>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else if (SINGLE == 2)
-            edit_chain<2, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+            edit_chain<2, 1>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else if (SINGLE == 0)
             edit_chain<2>(r, g, b, active, LdsMaskParams{a.ed.mp, LDS_MP}, a.ed.num_masks, luts, tabs);
         else
@@ -1703,11 +1705,18 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
         if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // variant 12 (A/B): run-time flags also for a pristine "main"
             return run_fused<256, MODE_DEVELOP_1P, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
-        if ((ed.mp[0].flags & MF_HUE_IDENTITY) && cfg.variant != 11)  // variant 11 (A/B): sincos_hue also for an identity hue curve
-            return lut ? run_fused<1024, MODE_DEVELOP_1H, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
-                       : run_fused<256, MODE_DEVELOP_1H, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
-        return lut ? run_fused<1024, MODE_DEVELOP_1, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
-                   : run_fused<256, MODE_DEVELOP_1, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
+        // hue / saturation / lightness curves that are not all trivial come folded into the editor's fused hue table
+        // (MODE_DEVELOP_1); without such curves the index is the new hue (MODE_DEVELOP_1H); variant 11 (A/B): the general
+        // multi-mask kernel for both
+        if (cfg.variant != 11) {
+            if (ed.hue_fused)
+                return lut ? run_fused<1024, MODE_DEVELOP_1, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
+                           : run_fused<256, MODE_DEVELOP_1, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
+            if (ed.mp[0].flags & MF_HUE_IDENTITY)
+                return lut ? run_fused<1024, MODE_DEVELOP_1H, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
+                           : run_fused<256, MODE_DEVELOP_1H, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
+            return hipErrorInvalidValue;  // a non-identity hue curve without its table: the API layer builds it
+        }
     }
     if (!lut && ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12) {  // user masks over an untouched "main"
         if (all_hue_identity(ed) && cfg.variant != 11)
@@ -1727,11 +1736,13 @@ static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_pack
     if (ed.num_masks == 1) {
         if (ed.mp[0].flags == MF_PRISTINE)
             return run_stream<256, MODE_DEVELOP_1P, false, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+        if (ed.hue_fused)  // "main"'s hue / saturation / lightness curves folded into the hue table
+            return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
+                       : run_stream<256, MODE_DEVELOP_1, false, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
         if (ed.mp[0].flags & MF_HUE_IDENTITY)
             return lut ? run_stream<1024, MODE_DEVELOP_1H, true, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
                        : run_stream<256, MODE_DEVELOP_1H, false, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
-        return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
-                   : run_stream<256, MODE_DEVELOP_1, false, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+        return hipErrorInvalidValue;  // a non-identity hue curve without its table: the API layer builds it
     }
     if (!lut && ed.mp[0].flags == MF_PRISTINE) {
         if (all_hue_identity(ed))
@@ -1854,6 +1865,8 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
         // costs more than sincos_hue saves — D 0.234 -> 0.249 ms)
         if (lens) return lut ? run_apply<true, true, OUTFMT, 1>(cfg, a, s) : run_apply<false, true, OUTFMT, 1>(cfg, a, s);
         if (a.ed.mp[0].flags == MF_PRISTINE && a.ed.flags == 0) return run_apply<false, false, OUTFMT, 3>(cfg, a, s);
+        // (the fused hue table, edit_chain's HUE_MODE 2, is the fused develop kernels' only: behind this kernel's 16-B/px
+        // input stream its dense 48-byte gather costs more than it saves — set G 0.269 -> 0.309 ms — as HUE_DIRECT does)
         return lut ? run_apply<true, false, OUTFMT, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 1>(cfg, a, s);
     }
     if (lens) return lut ? run_apply<true, true, OUTFMT, 0>(cfg, a, s) : run_apply<false, true, OUTFMT, 0>(cfg, a, s);
@@ -1920,6 +1933,35 @@ hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t wi
         break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// The fused hue table of an editor with one mask (rpf_math.h HueFused): for every hue index j the boundary direction (from
+// the processor's table) and what the chain takes from "main"'s curves at j — cos / sin of the hue curve[j] maps to, the
+// saturation and lightness gains — computed with the chain's own functions (luts.hsl's quotients, sincos_hue), so a launch
+// that reads them has the bits of one that evaluates them.  table[-1]'s second half is a copy of index 65535's data.
+__global__ __launch_bounds__(256) void k_build_hue_fused(const HueBound* hb, const ushort4* hsl, MaskParams P, const MathTables* tabs,
+                                                         HueFused* table)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;  // 65536 threads
+    const ushort4 v = hsl[j];
+    HueFused e;
+    e.c = hb[j].c; e.s = hb[j].s;
+    e.sat_gain = (P.flags & MF_SAT_CONST) ? P.sat_gain : div_u16_by(v.y, 32767.5f, (float)(1.0 / 32767.5));
+    e.light_gain = (P.flags & MF_LIGHT_CONST) ? P.light_gain : div_u16_by(v.z, 32767.5f, (float)(1.0 / 32767.5));
+    sincos_hue(v.x, tabs->sc, e.cs, e.sn);
+    table[j] = e;
+    if (j == 65535u) {
+        HueFusedData* lead = reinterpret_cast<HueFusedData*>(table) - 1;
+        *lead = HueFusedData{e.cs, e.sn, e.sat_gain, e.light_gain};
+    }
+}
+
+hipError_t launch_build_hue_fused(const HueBound* d_hue_bounds, const ushort4* d_hsl_main, const MaskParams& main,
+                                  const MathTables* d_tabs, HueFused* d_table, hipStream_t s)
+{
+    if (!d_hue_bounds || !d_hsl_main || !d_tabs || !d_table) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_build_hue_fused, dim3(256), dim3(256), 0, s, d_hue_bounds, d_hsl_main, main, d_tabs, d_table);
     return hipGetLastError();
 }
 

@@ -396,6 +396,38 @@ RPF_HD uint32_t hue_index_cs(float y, float x, const HueBoundCs* hb, const TabT&
     return k;
 }
 
+// The table a launch with ONE mask and a non-identity hue curve reads (built per editor from "main"'s hue / saturation /
+// lightness curves: rpf_kernels.hip k_build_hue_fused): boundary j together with everything the chain wants from index j —
+// cos / sin of the hue angle the curve maps j to (what sincos_hue(curve[j]) returns) and the two gains (wgsl:324-331) — so that
+// ONE gather replaces the boundary lookup, the curve lookup that depends on it, two quotients and sincos_hue (four LDS reads,
+// eleven binary64 operations).  The data of index j - 1, wanted when the direction lies before boundary j, are the 16 bytes
+// in front of entry j (entry j - 1's second half; entry 0 has a copy of index 65535's in front of it): the 48 bytes read lie
+// in one 128-byte line for three entries out of four.
+struct HueFused {
+    double c, s;                         // direction of the boundary at which the index first reaches j
+    float cs, sn, sat_gain, light_gain;  // of index j
+};
+struct HueFusedData { float cs, sn, sat_gain, light_gain; };
+
+template <bool NEG_ZERO_X = true>
+RPF_HD uint32_t hue_index_fused(float y, float x, const HueFused* hf, float& cs, float& sn, float& sat_gain, float& light_gain)
+{
+    static_assert(!NEG_ZERO_X, "the chain's promise (x is never -0): the k = 32767 corner has no entry of its own");
+    float mx;
+    const float v = hue_candidate(y, x, mx);
+    const float vr = v + 8388608.0f;
+    const uint32_t j = f2bits(vr) & 0xffffu;
+    const HueFused bd = hf[j];
+    const HueFusedData prev = reinterpret_cast<const HueFusedData*>(hf + j)[-1];
+    const double d = __builtin_fma((double)y, bd.c, -((double)x * bd.s));
+    const bool passed = d >= 0.0;
+    cs = passed ? bd.cs : prev.cs;
+    sn = passed ? bd.sn : prev.sn;
+    sat_gain = passed ? bd.sat_gain : prev.sat_gain;
+    light_gain = passed ? bd.light_gain : prev.light_gain;
+    return (j - (passed ? 0u : 1u)) & 0xffffu;
+}
+
 // Correctly rounded binary32 square root (wgsl:70 `sqrt`, wgsl:170 `length`).  The compiler's IEEE expansion of
 // sqrtf costs 16 instructions on gfx950 (scaling for subnormal inputs, v_sqrt_f32, two trial residuals, four selects).
 // For s in [2^-96, 2^96) none of the scaling is needed and one Markstein step does it: y0 = s g with g = v_rsq_f32(s)

@@ -220,6 +220,37 @@ def test_apply_is_repeatable_and_tracks_setters(gpu):
         assert_parity(first, O.apply(rgba, [p]))
 
 
+def test_fused_hue_table_follows_the_curves(gpu):
+    """One mask with hue / saturation / lightness curves: the fused develop kernel reads them folded into the editor's
+    hue table (rpf_math.h HueFused), which has to be rebuilt exactly when what it is made of changes — another hue curve,
+    an identity hue curve with the other two left, constant curves (no table), a second mask (no table) and back."""
+    import copy
+    h, w = 46, 130
+    cfa = util.bayer_natural(h, w)
+    rp = util.raw_params()
+    ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+    g = util.params_G()
+    steps = [g]
+    p = copy.deepcopy(g); p.hue_tone_curve = np.roll(np.asarray(g.hue_tone_curve), 1234).tolist(); steps.append(p)      # another hue curve
+    p = copy.deepcopy(g); p.hue_tone_curve = list(range(65536)); steps.append(p)                                       # identity hue, the others stay
+    p = copy.deepcopy(g); p.saturation_tone_curve = [40000] * 65536; p.lightness_tone_curve = [30000] * 65536; steps.append(p)   # constant gains
+    steps += [util.params_S(), g]                                                                                        # no curves at all, and back
+    for p in steps:
+        util.configure_editor(ed, p)
+        ed.apply_adjustments()
+        assert_parity(ed.rgba(), O.develop(cfa, rp, [p]))
+    rng = np.random.default_rng(3)
+    mask = rng.random((h, w), dtype=np.float32)
+    ed.add_mask("m1", mask)
+    util.configure_editor(ed, util.params_S(), mask_name="m1", main=False)
+    ed.apply_adjustments()                                                   # two masks: the general kernel, no table
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(mask, g.mask_range)])
+    assert_parity(ed.rgba(), O.develop(cfa, rp, [g, util.params_S()], masks=masks))
+    ed.remove_mask("m1")
+    ed.apply_adjustments()                                                   # one mask again: the table as it was
+    assert_parity(ed.rgba(), O.develop(cfa, rp, [g]))
+
+
 # ---- device-pointer layer: row tiles with halos, output formats -------------------------------
 def test_row_tiles_with_halo_equal_whole_frame(gpu):
     torch = pytest.importorskip("torch")
