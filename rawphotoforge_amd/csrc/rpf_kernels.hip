@@ -289,17 +289,37 @@ __device__ __forceinline__ uint32_t active_masks(const DeviceEdit& ed, size_t pi
     return 1u | ((uint32_t)ed.mask_bits[pix] << 1);
 }
 
-__device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T, uint16_t* lut, bool with_lut, int tid,
-                                             int nt)
+// N16 16-byte words from global memory to LDS by the NT threads of a workgroup, up to eight loads per thread in flight
+// before the first is waited for: written as `for (i = tid; i < n; i += nt) dst[i] = src[i]` the compiler emits a loop
+// with a full wait per trip — one L2 round trip (~1 us) per trip, at the start of every launch.
+template <int NT, int N16>
+__device__ __forceinline__ void stage16(const uint4* __restrict__ src, uint4* __restrict__ dst, int tid)
 {
-    const uint4* src = reinterpret_cast<const uint4*>(ed.tabs);
-    uint4* dst = reinterpret_cast<uint4*>(T);
-    for (int i = tid; i < (int)(sizeof(MathTables) / 16); i += nt) dst[i] = src[i];
-    if (with_lut) {
-        const uint4* ls = reinterpret_cast<const uint4*>(ed.bright);
-        uint4* ld = reinterpret_cast<uint4*>(lut);
-        for (int i = tid; i < RPF_CURVE_RESOLUTION * 2 / 16; i += nt) ld[i] = ls[i];
+    constexpr int CH = 8;
+#pragma unroll
+    for (int base = 0; base < N16; base += NT * CH) {
+        uint4 v[CH];
+        int idx[CH];
+        // a thread past the end of a partial last chunk copies the last word again (same value to the same address):
+        // no branch, so nothing keeps the loads from being issued together
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int i = base + k * NT + tid;
+            idx[k] = (base + (k + 1) * NT <= N16 || i < N16) ? i : N16 - 1;
+            if (base + k * NT < N16) v[k] = src[idx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (base + k * NT < N16) dst[idx[k]] = v[k];
     }
+}
+
+template <int NT, bool WITH_LUT>
+__device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T, uint16_t* lut, int tid)
+{
+    stage16<NT, (int)(sizeof(MathTables) / 16)>(reinterpret_cast<const uint4*>(ed.tabs), reinterpret_cast<uint4*>(T), tid);
+    if (WITH_LUT)
+        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(ed.bright), reinterpret_cast<uint4*>(lut), tid);
 }
 
 // The edit chain on a pixel pair in the depth of specialisation MODE names (see the enum above).
@@ -462,7 +482,7 @@ void k_stream(const StreamArgs a)
     constexpr bool MULTI = mode_multi(MODE);
     if (MODE != MODE_DEMOSAIC) {
         assert_lds_base(smem);
-        stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+        stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
         if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
@@ -729,7 +749,7 @@ void k_hp(const StreamArgs a)
     constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     constexpr bool MULTI = mode_multi(MODE);
     assert_lds_base(smem);
-    stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+    stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
     if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();  // the only barrier of the kernel
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
@@ -920,7 +940,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a)
     const int y0 = (int)a.g.y0, rows = (int)a.g.rows;
     if (MODE == MODE_DEVELOP) {
         assert_lds_base(smem);
-        stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+        stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
     }
     const LdsTabs tabs((uint32_t)((TILE_ELEMS * 4 + 15) & ~15), T, a.ed.mp[0], false);
     const int lx = tid & (TILE_W - 1);
@@ -1005,7 +1025,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     const int tid = threadIdx.x;
     constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     assert_lds_base(smem);
-    stage_tables(a.ed, T, lut, LDS_LUT, tid, NT);
+    stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
     if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
