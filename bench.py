@@ -529,7 +529,8 @@ def main():
         dev_s = make_developer(configure_with(syn.PARAM_SETS["S"]))
         sec["edit_set_S"] = entry(*timed(lambda: dev_s.step(band, out, out_fmt, out_bpp, False), nsec),
                                   "same frame (Infinity-Cache-resident), edit set S: run-time flags, brightness curve staged "
-                                  "in LDS, vignette, all tone sliders — the kernel a user's edits dispatch")
+                                  "in LDS, vignette (its position-only part read from the editor's falloff map: +4 B/px of traffic), all tone "
+                                  "sliders — the kernel a user's edits dispatch")
         del dev_s
         npool = 8
         frames = [band] + [tiles.make_band_buffer(gen(rows, W, seed=20260700 + i), device="cuda") for i in range(1, npool)]
