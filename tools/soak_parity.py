@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Soak: random edit states (tests/util.random_params: every combination of the identity- / constant-curve fast paths), random
+frame sizes, CFA patterns, mask counts and row bands, for a given number of seconds, the GPU against the oracle bit for bit.
+The same comparison as tests/test_gpu_parity.py::test_random_parameter_space_on_gpu, longer and wider — test
+infrastructure (it drives the oracle), run by hand on the GPU box:  python tools/soak_parity.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import rawphotoforge_amd as R
+import oracle as O
+from tests import util
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
+gpu = R.GpuProcessor(0)
+t_end = time.time() + seconds
+n = bad = 0
+kinds = {}
+while time.time() < t_end:
+    h, w = int(rng.integers(3, 140)), int(rng.integers(3, 420))
+    n_masks = int(rng.choice([1, 1, 1, 2, 3]))
+    params = [util.random_params(rng) for _ in range(n_masks)]
+    params[0].vignette = 0 if rng.random() < 0.4 else int(rng.integers(-100, 101))
+    masks = np.ones((n_masks, h, w), np.float32)
+    raw_masks = []
+    for m in range(1, n_masks):
+        mm = rng.random((h, w)).astype(np.float32) - np.float32(0.3)
+        raw_masks.append(mm)
+        masks[m] = O.binarize_mask(mm)
+    bayer = rng.random() < 0.7
+    if bayer:
+        cfa = util.bayer_natural(h, w, seed=int(rng.integers(1 << 30)))
+        rp = O.RawParams(cfa_pattern=int(rng.integers(0, 4)))
+        ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+        want = O.develop(cfa, rp, params, masks=masks)
+    else:
+        img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(1.2) - np.float32(0.05))
+        ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+        want = O.apply(np.concatenate([img, np.ones((h, w, 1), np.float32)], -1), params, masks=masks)
+    for m in range(1, n_masks):
+        ed.add_mask(f"m{m}", raw_masks[m - 1])
+    for m, p in enumerate(params):
+        util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
+    ed.apply_adjustments()
+    got = np.asarray(ed.rgba(), np.float32).reshape(want.shape)
+    d = util.ulp_diff(got, want)
+    n += 1
+    key = ("bayer" if bayer else "rgb", n_masks, params[0].vignette != 0)
+    kinds[key] = kinds.get(key, 0) + 1
+    if d.max() != 0:
+        bad += 1
+        print(f"MISMATCH case {n}: {h}x{w} {key}: {int((d > 0).sum())} values, max {int(d.max())} ulp", flush=True)
+    if n % 50 == 0:
+        print(f"{n} cases, {bad} mismatches", flush=True)
+print(f"soak done: {n} cases in {seconds:.0f} s, {bad} mismatches; by (source, masks, vignette): {sorted(kinds.items())}")
+sys.exit(1 if bad else 0)
