@@ -327,6 +327,22 @@ template <class Tabs> RPF_HD float chain_k_gamma_off(const Tabs&) { return RPF_F
 template <class Tabs> RPF_HD float chain_main_sat(const Tabs&, const MaskParams& P) { return P.sat_gain; }
 template <class Tabs> RPF_HD float chain_main_light(const Tabs&, const MaskParams& P) { return P.light_gain; }
 
+// One entry of the fused hue table (rpf_math.h HueFused) of an editor whose only mask is `P`: boundary j and what the chain
+// takes from "main"'s curves at index j — the Luts::hsl quotients and sincos_hue of the hue the curve maps j to.  The
+// table is built with this function (rpf_kernels.hip k_build_hue_fused; the host twin), a launch that reads it has the
+// bits of one that evaluates the same expressions per pixel.
+template <class SinCos>
+RPF_HD HueFused hue_fused_entry(const HueBound& hb, uint32_t hue_v, uint32_t sat_v, uint32_t light_v, const MaskParams& P,
+                                const SinCos& S)
+{
+    HueFused e;
+    e.c = hb.c; e.s = hb.s;
+    e.sat_gain = (P.flags & MF_SAT_CONST) ? P.sat_gain : div_u16_by(sat_v, 32767.5f, (float)(1.0 / 32767.5));
+    e.light_gain = (P.flags & MF_LIGHT_CONST) ? P.light_gain : div_u16_by(light_v, 32767.5f, (float)(1.0 / 32767.5));
+    sincos_hue(hue_v, S, e.cs, e.sn);
+    return e;
+}
+
 // STATIC_FLAGS (>= 0): "main"'s flag word, known at compile time (the caller's promise that mp[0].flags equals it).
 template <int N, int HUE_MODE = 0, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
 RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],

@@ -1965,11 +1965,7 @@ __global__ __launch_bounds__(256) void k_build_hue_fused(const HueBound* hb, con
 {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;  // 65536 threads
     const ushort4 v = hsl[j];
-    HueFused e;
-    e.c = hb[j].c; e.s = hb[j].s;
-    e.sat_gain = (P.flags & MF_SAT_CONST) ? P.sat_gain : div_u16_by(v.y, 32767.5f, (float)(1.0 / 32767.5));
-    e.light_gain = (P.flags & MF_LIGHT_CONST) ? P.light_gain : div_u16_by(v.z, 32767.5f, (float)(1.0 / 32767.5));
-    sincos_hue(v.x, tabs->sc, e.cs, e.sn);
+    const HueFused e = hue_fused_entry(hb[j], v.x, v.y, v.z, P, tabs->sc);
     table[j] = e;
     if (j == 65535u) {
         HueFusedData* lead = reinterpret_cast<HueFusedData*>(table) - 1;

@@ -59,6 +59,26 @@ def test_random_parameter_space():
         _check([util.random_params(rng) for _ in range(n_masks)], n=20_000, seed=int(rng.integers(1 << 30)))
 
 
+def test_fused_hue_table_equals_the_per_pixel_evaluation():
+    """One mask: the chain with that mask's hue / saturation / lightness curves, their quotients and sincos_hue read from the
+    fused hue table (edit_chain's HUE_MODE 2 — what the fused develop kernels run) against the oracle, bit for bit: set G,
+    an identity hue curve with the other two left, constant gains, and random single-mask parameter sets."""
+    import copy
+    g = util.params_G()
+    cases = [g]
+    p = copy.deepcopy(g); p.hue_tone_curve = list(range(65536)); cases.append(p)
+    p = copy.deepcopy(g); p.saturation_tone_curve = [40000] * 65536; p.lightness_tone_curve = [30000] * 65536; cases.append(p)
+    rng = np.random.default_rng(99)
+    cases += [util.random_params(rng, trivial_prob=0.2) for _ in range(12)]
+    for i, p in enumerate(cases):
+        n = 200_000 if i < 3 else 20_000
+        rgb = _pixels(n, 40 + i)
+        img = np.concatenate([rgb, np.ones((n, 1), np.float32)], 1).reshape(1, n, 4)
+        want = O.apply(img, [p]).reshape(n, 4)
+        got = util.twin_apply(rgb, [p], fused=True)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), i
+
+
 def test_demosaic_formulas_with_carried_powers_of_two_equal_the_specification():
     """rpf_chain.h evaluates the four Malvar-He-Cutler values with the division by 8 carried into the terms and every
     'power of two times a term, plus a term' as one fma (19 instead of 29 instructions per pixel pair).  DESIGN.md §3 /

@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <vector>
+
 namespace rpf {
 void build_math_tables(MathTables& T);
 void build_legacy_tables(LegacyTables& T);
@@ -51,6 +53,8 @@ static const rpf::HueBound* hue_bounds_tab() { return hue_tabs().b; }
 
 struct HostLuts {
     const int32_t* bright; const int32_t* hue; const int32_t* sat; const int32_t* light;
+    const rpf::HueFused* fused = nullptr;  // edit_chain's HUE_MODE 2 (twin_apply_fused)
+    const rpf::HueFused* hue_fused() const { return fused; }
     static uint32_t fetch(const int32_t* l, uint32_t m, uint32_t i)
     {
         int32_t v = l[(size_t)m * RPF_CURVE_RESOLUTION + i];
@@ -157,6 +161,31 @@ void twin_edit_chain(const float* rgb, size_t npix, const rpf::MaskParams* mp, u
     }
 }
 
+// The same chain for ONE mask with its hue / saturation / lightness curves folded into the fused hue table (edit_chain's
+// HUE_MODE 2, what the fused develop kernels run for such an editor): the table is built here as k_build_hue_fused builds it.
+void twin_edit_chain_fused(const float* rgb, size_t npix, const rpf::MaskParams* mp, const int32_t* bright, const int32_t* hue,
+                           const int32_t* sat, const int32_t* light, float* rgba_out)
+{
+    HostLuts L{bright, hue, sat, light};
+    const rpf::MathTables& T = tabs();
+    // (one HueFusedData in front of entry 0: index 65535's data)
+    std::vector<rpf::HueFused> store(RPF_CURVE_RESOLUTION + 1);
+    rpf::HueFused* table = store.data() + 1;
+    for (uint32_t j = 0; j < RPF_CURVE_RESOLUTION; ++j)
+        table[j] = rpf::hue_fused_entry(hue_bounds_tab()[j], HostLuts::fetch(hue, 0, j), HostLuts::fetch(sat, 0, j),
+                                        HostLuts::fetch(light, 0, j), mp[0], T.sc);
+    reinterpret_cast<rpf::HueFusedData*>(table)[-1] =
+        rpf::HueFusedData{table[65535].cs, table[65535].sn, table[65535].sat_gain, table[65535].light_gain};
+    L.fused = table;
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)npix; ++i) {
+        float r[1] = {rgb[i * 3]}, g[1] = {rgb[i * 3 + 1]}, b[1] = {rgb[i * 3 + 2]};
+        const uint32_t act[1] = {1u};
+        rpf::edit_chain<1, 2>(r, g, b, act, mp, 1u, L, T);
+        rgba_out[i * 4] = r[0]; rgba_out[i * 4 + 1] = g[0]; rgba_out[i * 4 + 2] = b[0]; rgba_out[i * 4 + 3] = 1.0f;
+    }
+}
+
 size_t twin_sizeof_mask_params(void) { return sizeof(rpf::MaskParams); }
 }
 
@@ -173,9 +202,9 @@ struct twin_edit_params {  // same layout as oracle's orc_edit_params
 
 // rgb: npix x 3 linear input; luts: num_masks x 65536 each.  Runs make_mask_params (the product's
 // host code) + edit_chain (the kernels' arithmetic) on the CPU.
-void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint32_t num_masks,
-                const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
-                float* rgba_out)
+void twin_apply_mode(const float* rgb, size_t npix, const twin_edit_params* ep, uint32_t num_masks,
+                     const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
+                     float* rgba_out, int fused)   // fused != 0 (num_masks == 1): through the fused hue table
 {
     std::vector<rpf::MaskParams> mp(num_masks);
     for (uint32_t m = 0; m < num_masks; ++m) {
@@ -188,7 +217,15 @@ void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint3
             p.curve[c].assign(src[c] + (size_t)m * RPF_CURVE_RESOLUTION, src[c] + (size_t)(m + 1) * RPF_CURVE_RESOLUTION);
         mp[m] = rpf::make_mask_params(p);
     }
-    twin_edit_chain(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
+    if (fused) twin_edit_chain_fused(rgb, npix, mp.data(), bright, hue, sat, light, rgba_out);
+    else twin_edit_chain(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
+}
+
+void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint32_t num_masks,
+                const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
+                float* rgba_out)
+{
+    twin_apply_mode(rgb, npix, ep, num_masks, bright, hue, sat, light, rgba_out, 0);
 }
 }
 

@@ -66,16 +66,18 @@ def twin():
     return _twin
 
 
-def twin_apply(rgb, masks_params) -> np.ndarray:
-    """Device arithmetic (rpf_chain.h) + the product's host parameter packing, on the CPU."""
+def twin_apply(rgb, masks_params, fused=False) -> np.ndarray:
+    """Device arithmetic (rpf_chain.h) + the product's host parameter packing, on the CPU.  fused=True (one mask): the
+    chain as the fused develop kernels run it when the mask's hue / saturation / lightness curves are folded into the
+    fused hue table (edit_chain's HUE_MODE 2)."""
     n = len(masks_params)
     a = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
     ep = (O.EditParamsC * n)(*[p.to_c() for p in masks_params])
     luts = [np.stack([np.asarray(getattr(p, nm), np.int32) for p in masks_params])
             for nm in ("brightness_tone_curve", "hue_tone_curve", "saturation_tone_curve", "lightness_tone_curve")]
     out = np.empty((a.shape[0], 4), np.float32)
-    twin().twin_apply(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.shape[0]), ep, C.c_uint32(n),
-                      *[l.ctypes.data_as(C.c_void_p) for l in luts], out.ctypes.data_as(C.c_void_p))
+    twin().twin_apply_mode(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.shape[0]), ep, C.c_uint32(n),
+                           *[l.ctypes.data_as(C.c_void_p) for l in luts], out.ctypes.data_as(C.c_void_p), C.c_int(1 if fused else 0))
     return out
 
 
