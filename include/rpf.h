@@ -350,7 +350,8 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
  * and band buffers must stay valid until the step's stream has passed it.
  * rpf_shard_flush: blocks until every step handed over has been ENQUEUED on its stream (then hipStreamSynchronize or an
  * event of the caller's is meaningful) and reports the first failure of such a step.
- * rpf_shard_timing: flush, wait for the timed launches, return their number and summed duration since the last call. */
+ * rpf_shard_timing: flush, wait for the timed launches, return their number and summed duration since the last call
+ * (at most 4096 launches are kept between two calls; further RPF_SHARD_TIMED steps run untimed). */
 int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
                             const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags);
 int rpf_shard_flush(rpf_shard* s);

@@ -282,11 +282,13 @@ int run_step(rpf_shard* s, const rpf_shard::Step& t)
     int rc = RPF_OK;
     if (t.exchange && (rc = enqueue_exchange(s, const_cast<unsigned char*>(t.b.band), t.row_bytes, t.rows, t.stream))) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    if (t.timed) {
+    bool timed = t.timed;
+    if (timed) {
         std::lock_guard<std::mutex> lock(s->mu);
-        if (!s->timing_free.empty()) { ev = s->timing_free.back(); s->timing_free.pop_back(); }
+        if (s->timing.size() >= 4096) timed = false;  // nobody has collected them (rpf_shard_timing): stop adding events
+        else if (!s->timing_free.empty()) { ev = s->timing_free.back(); s->timing_free.pop_back(); }
     }
-    if (t.timed && !ev.first) {
+    if (timed && !ev.first) {
         HIP_TRY(hipEventCreate(&ev.first));
         HIP_TRY(hipEventCreate(&ev.second));
     }
@@ -295,7 +297,7 @@ int run_step(rpf_shard* s, const rpf_shard::Step& t)
     // fill theirs), and a persistent workgroup that has to wait for that CU makes its whole launch late.
     static const int reserve = getenv("RPF_SHARD_ASYNC_RESERVE") ? atoi(getenv("RPF_SHARD_ASYNC_RESERVE")) : 8;
     HIP_TRY(launch_part(t.b, PART_ALL, t.stream, ev.second, ev.first, t.exchange ? reserve : 0));
-    if (t.timed) {
+    if (timed) {
         std::lock_guard<std::mutex> lock(s->mu);
         s->timing.push_back(ev);
     }
