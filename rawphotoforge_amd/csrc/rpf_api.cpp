@@ -185,8 +185,8 @@ static int sync_edit_state_impl(rpf_editor* e)
             if (!same) {
                 if ((rc = quiesce())) return rc;
                 if (!e->d_hue_fused_alloc)
-                    HIP_TRY(hipMalloc(&e->d_hue_fused_alloc, sizeof(HueFusedData) + (size_t)RPF_CURVE_RESOLUTION * sizeof(HueFused)));
-                HueFused* t = reinterpret_cast<HueFused*>(static_cast<char*>(e->d_hue_fused_alloc) + sizeof(HueFusedData));
+                    HIP_TRY(hipMalloc(&e->d_hue_fused_alloc, (size_t)RPF_CURVE_RESOLUTION * sizeof(HueFused)));
+                HueFused* t = static_cast<HueFused*>(e->d_hue_fused_alloc);
                 HIP_TRY(launch_build_hue_fused(e->proc->d_hue_bounds, e->d_hsl, P0, e->proc->d_tabs, t, e->stream));
                 HIP_TRY(hipStreamSynchronize(e->stream));  // rpf_dev_* callers launch on their own streams
                 e->hue_fused_valid = true;
@@ -197,7 +197,7 @@ static int sync_edit_state_impl(rpf_editor* e)
                 e->hue_fused_stamp[2] = p0.curve_ver[RPF_CURVE_LIGHTNESS];
             }
         }
-        e->dev.hue_fused = use ? reinterpret_cast<const HueFused*>(static_cast<char*>(e->d_hue_fused_alloc) + sizeof(HueFusedData)) : nullptr;
+        e->dev.hue_fused = use ? static_cast<const HueFused*>(e->d_hue_fused_alloc) : nullptr;
     }
     const rpf_gpu_edit_parameters g0 = convert_params(e->state.masks[0].params);
     e->dev.vign_strength = (-g0.vignette / 100.0f) * 2.0f;     // wgsl:167 (main mask only, :276)

@@ -371,7 +371,7 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
 
     // linear_srgb_to_oklch, wgsl:64-75.  The hue is only ever used as a curve index (hue_index, rpf_math.h).
     // HUE_MODE: 0 = any masks and curves; 1 = HUE_DIRECT (see above); 2 = HUE_FUSED: one mask whose curves are folded
-    // into the hue table (rpf_math.h HueFused): index, cos / sin of the NEW hue and both gains from one gather
+    // into the hue table (rpf_math.h HueFused): the index, then cos / sin of the NEW hue and both gains from its entry
     constexpr bool HUE_DIRECT = HUE_MODE == 1, HUE_FUSED = HUE_MODE == 2;
     float L[N], C[N], h[N], cs0[N], sn0[N], sg0[N], lg0[N];
     uint32_t hu0[N];

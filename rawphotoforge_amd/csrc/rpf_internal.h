@@ -47,8 +47,7 @@ struct rpf_editor {
     ushort4* d_hsl = nullptr;
     uint8_t* d_masks = nullptr;       // user-mask planes as uploaded (u8, binarised)
     uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
-    // one mask with non-trivial hue / saturation / lightness curves: the fused hue table (allocation starts 16 bytes, one
-    // HueFusedData, before entry 0) and what it was built from
+    // one mask with non-trivial hue / saturation / lightness curves: the fused hue table and what it was built from
     void* d_hue_fused_alloc = nullptr;
     uint64_t hue_fused_stamp[3] = {~0ull, ~0ull, ~0ull};  // curve versions (hue, saturation, lightness) of "main"
     uint32_t hue_fused_flags = 0;

@@ -1136,6 +1136,8 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
             edit_chain<2, 1>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else if (SINGLE == 0)
             edit_chain<2>(r, g, b, active, LdsMaskParams{a.ed.mp, LDS_MP}, a.ed.num_masks, luts, tabs);
+        else if (SINGLE == 4)  // one mask with hue / saturation / lightness curves: through the editor's fused hue table
+            edit_chain<2, 2>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else
             edit_chain<2>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
@@ -1885,8 +1887,9 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
         // costs more than sincos_hue saves — D 0.234 -> 0.249 ms)
         if (lens) return lut ? run_apply<true, true, OUTFMT, 1>(cfg, a, s) : run_apply<false, true, OUTFMT, 1>(cfg, a, s);
         if (a.ed.mp[0].flags == MF_PRISTINE && a.ed.flags == 0) return run_apply<false, false, OUTFMT, 3>(cfg, a, s);
-        // (the fused hue table, edit_chain's HUE_MODE 2, is the fused develop kernels' only: behind this kernel's 16-B/px
-        // input stream its dense 48-byte gather costs more than it saves — set G 0.269 -> 0.309 ms — as HUE_DIRECT does)
+        // hue / saturation / lightness curves that are not all trivial: through the editor's fused hue table
+        if (a.ed.hue_fused)
+            return lut ? run_apply<true, false, OUTFMT, 4>(cfg, a, s) : run_apply<false, false, OUTFMT, 4>(cfg, a, s);
         return lut ? run_apply<true, false, OUTFMT, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 1>(cfg, a, s);
     }
     if (lens) return lut ? run_apply<true, true, OUTFMT, 0>(cfg, a, s) : run_apply<false, true, OUTFMT, 0>(cfg, a, s);
@@ -1959,18 +1962,13 @@ hipError_t launch_unpack(const uint8_t* d_packed, size_t row_stride, uint32_t wi
 // The fused hue table of an editor with one mask (rpf_math.h HueFused): for every hue index j the boundary direction (from
 // the processor's table) and what the chain takes from "main"'s curves at j — cos / sin of the hue curve[j] maps to, the
 // saturation and lightness gains — computed with the chain's own functions (luts.hsl's quotients, sincos_hue), so a launch
-// that reads them has the bits of one that evaluates them.  table[-1]'s second half is a copy of index 65535's data.
+// that reads them has the bits of one that evaluates them.
 __global__ __launch_bounds__(256) void k_build_hue_fused(const HueBound* hb, const ushort4* hsl, MaskParams P, const MathTables* tabs,
                                                          HueFused* table)
 {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;  // 65536 threads
     const ushort4 v = hsl[j];
-    const HueFused e = hue_fused_entry(hb[j], v.x, v.y, v.z, P, tabs->sc);
-    table[j] = e;
-    if (j == 65535u) {
-        HueFusedData* lead = reinterpret_cast<HueFusedData*>(table) - 1;
-        *lead = HueFusedData{e.cs, e.sn, e.sat_gain, e.light_gain};
-    }
+    table[j] = hue_fused_entry(hb[j], v.x, v.y, v.z, P, tabs->sc);
 }
 
 hipError_t launch_build_hue_fused(const HueBound* d_hue_bounds, const ushort4* d_hsl_main, const MaskParams& main,

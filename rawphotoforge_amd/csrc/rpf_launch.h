@@ -21,7 +21,7 @@ struct DeviceEdit {
     const HueBoundCs* hue_cs;    // the same boundaries with cos / sin of the hue angles attached (HUE_DIRECT launches)
     // One mask with hue / saturation / lightness curves that are not all trivial: the boundaries with what "main"'s
     // curves give at each index attached (rpf_math.h HueFused; per editor, rebuilt when those curves change).  Null
-    // otherwise.  Points at entry 0; the 16 bytes in front of it belong to the table.
+    // otherwise.
     const HueFused* hue_fused;
     float vign_strength;         // (-vignette / 100) * 2, 0 = off       wgsl:167
     // rows x width binary32: the vignette's falloff at every pixel of the tile (vignette_falloff_from_axes: a correctly
@@ -61,7 +61,7 @@ struct LaunchCfg {
 };
 
 // d_cfa: (rows + 4) x width u16, row r = frame row y0 - 2 + r
-// (d_table - 16 bytes .. d_table + 65536 entries) <- the fused hue table of an editor whose only mask is `main`
+// d_table[0 .. 65535] <- the fused hue table of an editor whose only mask is `main`
 hipError_t launch_build_hue_fused(const HueBound* d_hue_bounds, const ushort4* d_hsl_main, const MaskParams& main,
                                   const MathTables* d_tabs, HueFused* d_table, hipStream_t s);
 // d_map[r * width + x] = vignette_falloff_from_axes at frame pixel (x, y0 + r): DeviceEdit::vign_falloff of that tile

@@ -396,36 +396,37 @@ RPF_HD uint32_t hue_index_cs(float y, float x, const HueBoundCs* hb, const TabT&
     return k;
 }
 
-// The table a launch with ONE mask and a non-identity hue curve reads (built per editor from "main"'s hue / saturation /
-// lightness curves: rpf_kernels.hip k_build_hue_fused): boundary j together with everything the chain wants from index j —
-// cos / sin of the hue angle the curve maps j to (what sincos_hue(curve[j]) returns) and the two gains (wgsl:324-331) — so that
-// ONE gather replaces the boundary lookup, the curve lookup that depends on it, two quotients and sincos_hue (four LDS reads,
-// eleven binary64 operations).  The data of index j - 1, wanted when the direction lies before boundary j, are the 16 bytes
-// in front of entry j (entry j - 1's second half; entry 0 has a copy of index 65535's in front of it): the 48 bytes read lie
-// in one 128-byte line for three entries out of four.
+// The table a launch with ONE mask reads when that mask's hue / saturation / lightness curves are not all trivial (built
+// per editor from "main"'s curves: rpf_chain.h hue_fused_entry, rpf_kernels.hip k_build_hue_fused): boundary j together
+// with everything the chain wants from index j — cos / sin of the hue angle the curve maps j to (what sincos_hue(curve[j])
+// returns) and the two gains (wgsl:324-331).  Read the way hue_index reads its boundaries — the boundary only where the
+// candidate is near it (hue_index_core's SPARSE rule: 3 lanes of 8, the rest entry 0) — and then the 16 data bytes of the
+// index that came out, in place of the curve entry, its two quotients and sincos_hue (four LDS reads, eleven binary64
+// operations).  (Read densely — entry j and index j - 1's data with it, one 48-byte gather — the fused develop kernel
+// was 2 % slower and the RGBA pass 15 %: profiles/r03_experiments.md section 14.)
 struct HueFused {
     double c, s;                         // direction of the boundary at which the index first reaches j
     float cs, sn, sat_gain, light_gain;  // of index j
 };
-struct HueFusedData { float cs, sn, sat_gain, light_gain; };
 
 template <bool NEG_ZERO_X = true>
 RPF_HD uint32_t hue_index_fused(float y, float x, const HueFused* hf, float& cs, float& sn, float& sat_gain, float& light_gain)
 {
-    static_assert(!NEG_ZERO_X, "the chain's promise (x is never -0): the k = 32767 corner has no entry of its own");
+    static_assert(!NEG_ZERO_X, "the chain's promise (x is never -0): the k = 32767 corner is not handled here");
     float mx;
     const float v = hue_candidate(y, x, mx);
     const float vr = v + 8388608.0f;
     const uint32_t j = f2bits(vr) & 0xffffu;
-    const HueFused bd = hf[j];
-    const HueFusedData prev = reinterpret_cast<const HueFusedData*>(hf + j)[-1];
-    const double d = __builtin_fma((double)y, bd.c, -((double)x * bd.s));
-    const bool passed = d >= 0.0;
-    cs = passed ? bd.cs : prev.cs;
-    sn = passed ? bd.sn : prev.sn;
-    sat_gain = passed ? bd.sat_gain : prev.sat_gain;
-    light_gain = passed ? bd.light_gain : prev.light_gain;
-    return (j - (passed ? 0u : 1u)) & 0xffffu;
+    const float frac = v - (vr - 8388608.0f);  // exact: v - round(v); see hue_index_core for the 3/16
+    const bool near = __builtin_fabsf(frac) < 0.1875f;
+    const HueFused* e = hf + (near ? j : 0u);
+    const double bc = e->c, bs = e->s;
+    const double d = __builtin_fma((double)y, bc, -((double)x * bs));
+    const bool passed = near ? d >= 0.0 : frac >= 0.0f;
+    const uint32_t k = (j - (passed ? 0u : 1u)) & 0xffffu;
+    const HueFused* ek = hf + k;
+    cs = ek->cs; sn = ek->sn; sat_gain = ek->sat_gain; light_gain = ek->light_gain;
+    return k;
 }
 
 // Correctly rounded binary32 square root (wgsl:70 `sqrt`, wgsl:170 `length`).  The compiler's IEEE expansion of

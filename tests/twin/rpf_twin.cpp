@@ -168,14 +168,11 @@ void twin_edit_chain_fused(const float* rgb, size_t npix, const rpf::MaskParams*
 {
     HostLuts L{bright, hue, sat, light};
     const rpf::MathTables& T = tabs();
-    // (one HueFusedData in front of entry 0: index 65535's data)
-    std::vector<rpf::HueFused> store(RPF_CURVE_RESOLUTION + 1);
-    rpf::HueFused* table = store.data() + 1;
+    std::vector<rpf::HueFused> store(RPF_CURVE_RESOLUTION);
+    rpf::HueFused* table = store.data();
     for (uint32_t j = 0; j < RPF_CURVE_RESOLUTION; ++j)
         table[j] = rpf::hue_fused_entry(hue_bounds_tab()[j], HostLuts::fetch(hue, 0, j), HostLuts::fetch(sat, 0, j),
                                         HostLuts::fetch(light, 0, j), mp[0], T.sc);
-    reinterpret_cast<rpf::HueFusedData*>(table)[-1] =
-        rpf::HueFusedData{table[65535].cs, table[65535].sn, table[65535].sat_gain, table[65535].light_gain};
     L.fused = table;
 #pragma omp parallel for
     for (long long i = 0; i < (long long)npix; ++i) {
