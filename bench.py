@@ -40,10 +40,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--preheat", type=int, default=200,
+    ap.add_argument("--preheat", type=int, default=1000,
                     help="untimed steps before the W warmup steps (same count on every rank): an idle MI355X needs "
-                         "~50 launches (15 ms) to reach its steady clocks, and steady state is what a production "
-                         "service sees (profiles/r01_experiments.md)")
+                         "~50 launches (15 ms) to reach its clocks and a few hundred more to settle (a 20-step timed region "
+                         "reads 0.5-2 %% higher after 1000 preheat steps, 0.16 s, than after 200), and steady state is what "
+                         "a production service sees (profiles/r01_experiments.md)")
     ap.add_argument("--workload", default="develop",
                     choices=["develop", "demosaic", "apply", "unpack", "develop_packed", "batch"],
                     help="develop = BASELINE configs[2] (the headline); batch = configs[4]: a pool of --frames different "

@@ -28,7 +28,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     lines = [f"# rocprofv3 summary — {label}", "",
              "Source: `tools/gpu_pmc.sh` on one MI355X (gfx950): the default `bench.py` command (steps 400, warmup 50, "
-             "preheat 200; `--no-cpu-baseline --no-secondary`: without the CPU leg and without the `secondary` block, whose launches of "
+             "`--preheat 200` instead of the default 1000; `--no-cpu-baseline --no-secondary`: without the CPU leg and without the `secondary` block, whose launches of "
              "the same kernel on frames from HBM would be averaged into the headline kernel's row) under `rocprofv3 --kernel-trace --stats`, and, separately, "
              "`--kernel-trace --pmc ...` passes of `bench.py --steps 50 --warmup 10 --preheat 60`.", ""]
 
