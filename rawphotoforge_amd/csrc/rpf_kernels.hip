@@ -1664,6 +1664,9 @@ static hipError_t run_fused(bool hp, const LaunchCfg& cfg, const uint16_t* d_cfa
     // k_hp always as ONE 1024-thread workgroup per CU (the same four waves per SIMD as four 256-thread ones): the math
     // tables are then staged once per CU instead of four times — 7 instead of 29 MB of L2 -> LDS traffic per launch, which
     // is most of what a launch costs before its first pixel (variant 22, A/B: 256-thread workgroups)
+    // (a vignette without its falloff map — a tile of more than 2^30 pixels, whose map would not fit a buffer descriptor —
+    // goes to the column-per-lane kernel, which evaluates the falloff in place)
+    if (hp && ed->vign_strength != 0.0f && !ed->vign_falloff) hp = false;
     if (hp && cfg.variant != 22) return run_hp<1024, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s);
     return hp ? run_hp<NT, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s)
               : run_stream<NT, MODE, LDS_LUT, OUTFMT>(cfg, d_cfa, raw, g, ed, d_out, s);
