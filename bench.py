@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--params", default="D", choices=["D", "S", "G", "V", "T", "B", "C"])
     ap.add_argument("--data", default="U", choices=["U", "N"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast"],
+                    help="exact (default, the headline): every builtin correctly rounded, bit-identical to the oracle; fast = "
+                         "RPF_PRECISION_FAST (include/rpf.h rpf_set_precision): binary32-only builtins within 1 ulp, contracted "
+                         "matrix products — reported under secondary.fast_precision by the default command")
     ap.add_argument("--out", default="rgba", choices=["rgba", "rgb", "u8"], help="output layout of the fused kernel")
     ap.add_argument("--masks", type=int, default=1,
                     help="N = 1 GPU: total number of masks (main + N-1 user masks of blobs covering ~half of the frame, "
@@ -156,9 +160,10 @@ def main():
         cfa = gen(rows, W, seed=20260630 + rank)          # rank 0 at N = 1: THE frame
     band = tiles.make_band_buffer(cfa, device="cuda")   # (rows + 4, W) with halo rows
 
-    def configure_with(pspec):
+    def configure_with(pspec, precision=None):
         def configure(e):
             syn.configure(e, pspec)
+            e.set_precision(R.PRECISION_FAST if (precision or args.precision) == "fast" else R.PRECISION_EXACT)
             for m in range(1, args.masks):   # user masks: smooth blobs thresholded at 0.5 (mask_range 0 -> v >= 0 keeps all,
                 yy, xx = np.mgrid[0:rows, 0:W]  # so the blobs are shifted below zero outside)
                 blob = np.sin(xx * (0.002 * m) + m) * np.cos(yy * (0.003 * m) - m)
@@ -468,7 +473,7 @@ def main():
                                       "of step k+1 runs beside the kernel of step k; every step is one exchange + one launch)",
                          }[schedule] if sharded else "")),
             "mode": mode, "schedule": (("none (halo once)" if halo_once else schedule) if sharded else None), "input_resident": "hbm" if batch else "infinity_cache",
-            "variant": args.variant, "out": args.out, "preheat_steps": preheat_steps,
+            "variant": args.variant, "precision": args.precision, "out": args.out, "preheat_steps": preheat_steps,
             "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4), "kernel_ms_min": round(kern_ms[0], 4),
             "kernel_timing": (f"HIP-event pairs around {len(kern_ms)} of the {args.steps} timed "
                               + ("launches, by their own start / completion signals (hipExtLaunchKernelGGL events inside "
@@ -533,6 +538,33 @@ def main():
                                   "in LDS, vignette (its position-only part read from the editor's falloff map: +4 B/px of traffic), all tone "
                                   "sliders — the kernel a user's edits dispatch")
         del dev_s
+        if args.precision == "exact":
+            # RPF_PRECISION_FAST on the same frame and edit set: kernel time, and how far its pixels are from the exact
+            # kernel's (= the oracle's, bit for bit: tests/test_gpu_parity.py).  Up to the brightness curve the two kernels
+            # compute the same bits, so with this edit set the hue index is the only quantity that can flip.
+            dev_f = make_developer(configure_with(spec, "fast"))
+            fe = entry(*timed(lambda: dev_f.step(band, out, out_fmt, out_bpp, False), nsec),
+                       "RPF_PRECISION_FAST specialisation of the same fused kernel (rpf_fast.h: binary32-only pow / sqrt / cos / sin "
+                       "within 1 ulp, hue index from a binary32 polynomial, contracted 3x3 products), same frame, edit set "
+                       + args.params + "; NOT the headline: `value` is the exact kernel")
+            out_exact = torch.empty_like(out)
+            dev.step(band, out_exact, out_fmt, out_bpp, False)
+            dev_f.step(band, out, out_fmt, out_bpp, False)
+            torch.cuda.synchronize()
+            dd = (out[..., :3] - out_exact[..., :3]).abs().amax(dim=2)
+            ulp = (out[..., :3].contiguous().view(torch.int32) - out_exact[..., :3].contiguous().view(torch.int32)).abs()
+            hist = torch.bincount(ulp.flatten().clamp(max=8), minlength=9).tolist()
+            fe["against_exact_kernel"] = {
+                "pixels": int(dd.numel()), "bit_identical_pixels": round(float((dd == 0).sum()) / dd.numel(), 5),
+                "ulp_histogram_per_channel_0_to_8plus": [round(h / ulp.numel(), 5) for h in hist],
+                "median_ulp": float(ulp.flatten().float().median()),
+                "pixels_within_1e-5": round(float((dd <= 1e-5).sum()) / dd.numel(), 6),
+                "index_flip_rate": round(float((dd > 1e-5).sum()) / dd.numel(), 6),
+                "index_flip_rate_note": "share of pixels further than 1e-5 from the exact kernel's: a hue index that differs by one "
+                                        "moves the hue by 1/65535 of a turn (the brightness-curve indices cannot differ)",
+                "max_abs_difference": round(float(dd.max()), 7)}
+            sec["fast_precision"] = fe
+            del dev_f, out_exact, dd, ulp
         npool = 8
         frames = [band] + [tiles.make_band_buffer(gen(rows, W, seed=20260700 + i), device="cuda") for i in range(1, npool)]
         k = [0]
@@ -601,6 +633,10 @@ def main():
                        f"{sum(times) * cores:.0f} core-s); single thread on {args.cpu_rows} rows: "
                        f"{args.cpu_rows * W / 1e6 / c1:.3f} MP/s; python-legacy flavour (demosaic + WB + apply_gamma) "
                        f"on 512x512: {legacy[1]:.1f} MP/s on 1 thread, {legacy[cores]:.1f} MP/s on {cores}"),
+            # BASELINE configs[0] / north_star "python-legacy's CPU path timed on the node's own host cores": the oracle's
+            # restatement of python-legacy's demosaic + WB + apply_gamma (pinned by tests/golden/legacy_helpers.npz)
+            "legacy_512x512_mp_s_1t": round(legacy[1], 2), "legacy_512x512_mp_s_all_cores": round(legacy[cores], 2),
+            "legacy_cores": cores, "single_thread_mp_s": round(args.cpu_rows * W / 1e6 / c1, 3),
         }
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -196,6 +196,23 @@ int rpf_editor_create_preview(rpf_editor* src, uint32_t target_long_edge, rpf_ed
 enum { RPF_FLAVOUR_ACTIVE = 0, RPF_FLAVOUR_GODOT_LEGACY = 1 };
 int rpf_set_shader_flavour(rpf_editor* e, int flavour);
 
+/* How the builtins of the edit chain (pow, sqrt, atan2, cos, sin: wgpu_shader.wgsl:67, 70, 72, 78-79, 98) are evaluated.
+ * WGSL leaves their accuracy to the backend; the reference's result is therefore defined only up to that.
+ * RPF_PRECISION_EXACT (default): every builtin correctly rounded, every other operation one IEEE binary32 operation in
+ *   source order — bit-identical to the parity oracle on every input (what all parity claims of this library refer to).
+ * RPF_PRECISION_FAST: binary32 only.  pow, sqrt, cos, sin within 1 ulp of the correctly rounded value; the hue index from a
+ *   binary32 polynomial (differs from the exact index, by one, within 0.005 index units of a boundary: about 0.1 % of
+ *   directions); a * b + c contracted to an fma in the 3x3 colour matrices and the gamma's affine step.  Everything up to and
+ *   including the brightness curve stays bit-identical to EXACT.  Measured against the oracle on uniformly random frames:
+ *   median 1 ulp per channel, 99.6 % of the pixels within 1e-5, the rest (hue-index flips: the hue moves by one step of the
+ *   index scale, so a steep per-hue curve scales the difference) within 2e-3 for the default curves (tests/test_fast_math.py,
+ *   tests/test_gpu_fast.py).  A hint: launches that have no binary32 specialisation (user masks, packed input, the
+ *   RGBA pass) compute the exact chain.  Not versioned edit state: takes effect at the next apply / rpf_dev_* call.
+ *   No reference counterpart (wgpu has one precision, the driver's). */
+enum { RPF_PRECISION_EXACT = 0, RPF_PRECISION_FAST = 1 };
+int rpf_set_precision(rpf_editor* e, int precision);
+int rpf_get_precision(const rpf_editor* e, int* precision);
+
 int rpf_apply_adjustments(rpf_editor* e);
 int rpf_editor_sync(rpf_editor* e);
 

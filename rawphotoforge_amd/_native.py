@@ -34,6 +34,7 @@ ERR_TOO_MANY_MASKS = 33
 OUT_RGBA_F32, OUT_RGB_F32, OUT_RGB_U8 = 0, 1, 2
 CFA_RGGB, CFA_BGGR, CFA_GRBG, CFA_GBRG = 0, 1, 2, 3
 FLAVOUR_ACTIVE, FLAVOUR_GODOT_LEGACY = 0, 1
+PRECISION_EXACT, PRECISION_FAST = 0, 1
 PACK_MSB_FIRST, PACK_LSB_FIRST, PACK_MIPI = 0, 1, 2
 CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
 SHARD_ID_BYTES = 128
@@ -100,6 +101,8 @@ SYMBOLS = {
     "rpf_preview_size": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "rpf_editor_create_preview": (C.c_int, [_vp, C.c_uint32, _P(_vp)]),
     "rpf_set_shader_flavour": (C.c_int, [_vp, C.c_int]),
+    "rpf_set_precision": (C.c_int, [_vp, C.c_int]),
+    "rpf_get_precision": (C.c_int, [_vp, _P(C.c_int)]),
     "rpf_apply_adjustments": (C.c_int, [_vp]),
     "rpf_editor_sync": (C.c_int, [_vp]),
     "rpf_get_rgba_f32": (C.c_int, [_vp, _f32p]),

@@ -16,6 +16,7 @@ namespace rpf {
 void build_math_tables(MathTables& T);
 void build_legacy_tables(LegacyTables& T);
 void build_hue_bounds(HueBound* B, HueBoundCs* Cs, const MathTables& T);
+void build_fast_tables(FastTables& T);
 }
 
 using namespace rpf;
@@ -77,6 +78,7 @@ static void processor_unref(rpf_processor* p)
     if (hipSetDevice(p->device) == hipSuccess) {
         if (p->d_tabs) (void)hipFree(p->d_tabs);
         if (p->d_legacy) (void)hipFree(p->d_legacy);
+        if (p->d_fast_tabs) (void)hipFree(p->d_fast_tabs);
         if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
         if (p->d_hue_cs) (void)hipFree(p->d_hue_cs);
     }
@@ -101,6 +103,8 @@ int api_sync_edit_state(rpf_editor* e) { return sync_edit_state(e); }
 static int sync_edit_state_impl(rpf_editor* e)
 {
     const uint32_t n = (uint32_t)e->state.masks.size();
+    e->dev.precision = (uint32_t)e->precision;  // not versioned state: taken at every launch, like the shader flavour
+    e->dev.fast_tabs = e->proc->d_fast_tabs;
     // The vignette's falloff depends on the pixel's position alone: one map per editor (4 B per pixel), computed when the
     // slider first leaves 0 (active shader flavour: the Godot-legacy falloff is another function and is evaluated in
     // place), read by the kernels instead of a square root, a quotient and a pow(t, 1.5) per pixel.
@@ -333,9 +337,14 @@ int rpf_processor_create(int device, rpf_processor** out)
         e = hipMemcpy(p->d_hue_bounds, bounds.data(), bounds.size() * sizeof(HueBound), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_hue_cs, hcs.size() * sizeof(HueBoundCs));
     if (e == hipSuccess) e = hipMemcpy(p->d_hue_cs, hcs.data(), hcs.size() * sizeof(HueBoundCs), hipMemcpyHostToDevice);
+    std::unique_ptr<FastTables> fast(new FastTables);
+    build_fast_tables(*fast);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_fast_tabs, sizeof(FastTables));
+    if (e == hipSuccess) e = hipMemcpy(p->d_fast_tabs, fast.get(), sizeof(FastTables), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(p->d_tabs);
         if (p->d_legacy) (void)hipFree(p->d_legacy);
+        if (p->d_fast_tabs) (void)hipFree(p->d_fast_tabs);
         if (p->d_hue_bounds) (void)hipFree(p->d_hue_bounds);
         if (p->d_hue_cs) (void)hipFree(p->d_hue_cs);
         return hip_fail(e, "tables", RPF_ERR_GPU_INITIALIZATION);
@@ -623,6 +632,22 @@ int rpf_set_shader_flavour(rpf_editor* e, int flavour)
     if (flavour != RPF_FLAVOUR_ACTIVE && flavour != RPF_FLAVOUR_GODOT_LEGACY)
         return fail(RPF_ERR_INVALID_ARGUMENT, "unknown shader flavour");
     e->flavour = flavour;
+    return ok();
+}
+
+int rpf_set_precision(rpf_editor* e, int precision)
+{
+    if (!e) return fail(RPF_ERR_INVALID_ARGUMENT, "null editor");
+    if (precision != RPF_PRECISION_EXACT && precision != RPF_PRECISION_FAST)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "unknown precision");
+    e->precision = precision;
+    return ok();
+}
+
+int rpf_get_precision(const rpf_editor* e, int* precision)
+{
+    if (!e || !precision) return fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
+    *precision = e->precision;
     return ok();
 }
 

@@ -4,6 +4,7 @@
 // of rust/photo-editor/src/wgpu_shader.wgsl and must be compiled with
 // -ffp-contract=off; the transcendental builtins come from rpf_math.h.
 #pragma once
+#include "rpf_fast.h"
 #include "rpf_math.h"
 
 namespace rpf {
@@ -324,6 +325,7 @@ RPF_HD const MaskParams& mask_params_user(const MaskParams* mp, uint32_t m) { re
 // MathTables) gets the plain values; rpf_kernels.hip overloads them for LdsTabs.
 template <class Tabs> RPF_HD float chain_k_gamma_lin(const Tabs&) { return RPF_F(12.92); }
 template <class Tabs> RPF_HD float chain_k_gamma_off(const Tabs&) { return RPF_F(0.055); }
+template <class Tabs> RPF_HD float chain_k_gamma_mul(const Tabs&) { return RPF_F(1.055); }
 template <class Tabs> RPF_HD float chain_main_sat(const Tabs&, const MaskParams& P) { return P.sat_gain; }
 template <class Tabs> RPF_HD float chain_main_light(const Tabs&, const MaskParams& P) { return P.light_gain; }
 
@@ -449,6 +451,114 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
             // clamp(select(a, b)) == select(clamp(a), clamp(b)); written this way each clamp is the free output
             // modifier of the multiplication / addition in front of it instead of a v_max of its own
             const float hi = clamp01(RPF_F(1.055) * powc<POW_GAMMA>(c, T.gamma) - chain_k_gamma_off(T));  // unused when c <= thr
+            const float lo = clamp01(c * chain_k_gamma_lin(T));
+            out[k] = c <= RPF_F(0.0031308) ? lo : hi;
+        }
+        r[n] = out[0]; g[n] = out[1]; b[n] = out[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// RPF_PRECISION_FAST (include/rpf.h rpf_set_precision): wgsl main :279-336 with the builtins of rpf_fast.h.
+//
+// What stays as in edit_chain, bit for bit: everything up to and including the brightness curve (mask_rgb_stage: plain
+// binary32 arithmetic in the reference's order, the u32 conversions, the curve look-ups, k / 65535 as the IEEE quotient)
+// — so the brightness-curve indices never differ from the oracle's, and with identity OKLCH curves a pixel changes only
+// through the roundings below.  What changes after it:
+//   * pow, sqrt, cos / sin: within 1 ulp of the correctly rounded value instead of correctly rounded (rpf_fast.h);
+//   * the hue index from an eight-term binary32 polynomial alone: equal to the reference's index except within 0.005 index
+//     units of a boundary (0.1 % of uniformly distributed directions; the neighbouring index then);
+//   * a * b + c is contracted to one fma in the 3x3 matrix products, the chroma and the gamma's affine step — as a WGSL
+//     implementation may (and every GPU backend does) — in the reference's left-to-right order.
+// No binary64 instruction, no table outside LDS (the per-hue curves of a mask that has them are the one gather left).
+// ---------------------------------------------------------------------------
+RPF_HD float dot3_fast(float c0, float c1, float c2, float x, float y, float z)
+{
+    return __builtin_fmaf(c2, z, __builtin_fmaf(c1, y, c0 * x));
+}
+
+template <int N, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
+RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N], const Params& mp,
+                            uint32_t num_masks, const Luts& luts, const Tabs& T)
+{
+    mask_rgb_stage<N, STATIC_FLAGS>(mask_params_main(mp), 0u, luts, r, g, b, nullptr);
+    uint32_t any_active = 0;
+    for (int n = 0; n < N; ++n) any_active |= active[n];
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        uint32_t u = 0;
+        for (uint32_t m = 1; m < num_masks; ++m)
+            u |= (__builtin_amdgcn_ballot_w64((any_active >> m) & 1u) != 0ull) ? (1u << m) : 0u;
+        any_active = u | 1u;
+    }
+#endif
+    for (uint32_t m = 1; m < num_masks; ++m) {
+        if (!((any_active >> m) & 1u)) continue;
+        bool act[N];
+        for (int n = 0; n < N; ++n) act[n] = (active[n] >> m) & 1u;
+        mask_rgb_stage<N>(mask_params_user(mp, m), m, luts, r, g, b, act);
+    }
+
+    // linear_srgb_to_oklch, wgsl:64-75
+    float L[N], C[N], hk[N];  // hk: the hue as the integer k of h = k / 65535, held as binary32
+    for (int n = 0; n < N; ++n) {
+        const float l = dot3_fast(RPF_F(0.4122214708), RPF_F(0.5363325363), RPF_F(0.0514459929), r[n], g[n], b[n]);
+        const float mm = dot3_fast(RPF_F(0.2119034982), RPF_F(0.6806995451), RPF_F(0.1073969566), r[n], g[n], b[n]);
+        const float s = dot3_fast(RPF_F(0.0883024619), RPF_F(0.2817188376), RPF_F(0.6299787005), r[n], g[n], b[n]);
+        const float lc = powc_fast<POW_CBRT>(l, T.cbrt);
+        const float mc = powc_fast<POW_CBRT>(mm, T.cbrt);
+        const float sc = powc_fast<POW_CBRT>(s, T.cbrt);
+        L[n] = dot3_fast(RPF_F(0.2104542553), RPF_F(0.7936177850), RPF_F(-0.0040720468), lc, mc, sc);
+        const float A = dot3_fast(RPF_F(1.9779984951), RPF_F(-2.4285922050), RPF_F(0.4505937099), lc, mc, sc);
+        const float Bq = dot3_fast(RPF_F(0.0259040371), RPF_F(0.7827717662), RPF_F(-0.8086757660), lc, mc, sc);
+        C[n] = sqrt_fast(__builtin_fmaf(Bq, Bq, A * A));
+        hk[n] = __builtin_truncf(hue_position_fast(Bq, A));  // f32(u32(h * 65535)), wgsl:320
+    }
+
+    // per-mask OKLCH curves, wgsl:312-331
+    auto oklch_stage = [&](uint32_t m, bool main_mask) {
+        const MaskParams P = main_mask ? mask_params_main(mp) : mask_params_user(mp, m);
+        const uint32_t pflags = (main_mask && STATIC_FLAGS >= 0) ? (uint32_t)STATIC_FLAGS : P.flags;
+        const bool trivial = (pflags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
+                             (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
+        for (int n = 0; n < N; ++n) {
+            // a user mask re-derives the index from the hue the previous mask left, u32(f32(k / 65535) * 65535) — which is
+            // k again for every k (tests/test_fast_math.py), so the integer is carried instead
+            const float hu_f = hk[n];
+            float nh_f = hu_f;
+            float sat_gain = main_mask ? chain_main_sat(T, P) : P.sat_gain;
+            float light_gain = main_mask ? chain_main_light(T, P) : P.light_gain;
+            if (!trivial) {
+                uint32_t nh;
+                luts.hsl(m, (uint32_t)hu_f, P, nh, sat_gain, light_gain);
+                nh_f = (float)nh;
+            }
+            const bool on = main_mask ? true : (bool)((active[n] >> m) & 1u);
+            hk[n] = on ? nh_f : hk[n];
+            C[n] = on ? C[n] * sat_gain : C[n];
+            L[n] = on ? L[n] * light_gain : L[n];
+        }
+    };
+    oklch_stage(0u, true);
+    for (uint32_t m = 1; m < num_masks; ++m)
+        if ((any_active >> m) & 1u) oklch_stage(m, false);
+
+    // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336)
+    for (int n = 0; n < N; ++n) {
+        float cs, sn;
+        sincos_hue_fast(hk[n], cs, sn);
+        const float oa = C[n] * cs, ob = C[n] * sn;
+        const float l_ = __builtin_fmaf(RPF_F(0.2158037573), ob, __builtin_fmaf(RPF_F(0.3963377774), oa, L[n]));
+        const float m_ = __builtin_fmaf(RPF_F(-0.0638541728), ob, __builtin_fmaf(RPF_F(-0.1055613458), oa, L[n]));
+        const float s_ = __builtin_fmaf(RPF_F(-1.2914855480), ob, __builtin_fmaf(RPF_F(-0.0894841775), oa, L[n]));
+        const float l3 = l_ * l_ * l_, m3 = m_ * m_ * m_, s3 = s_ * s_ * s_;
+        const float lin[3] = {dot3_fast(RPF_F(4.0767416621), RPF_F(-3.3077115913), RPF_F(0.2309699292), l3, m3, s3),
+                              dot3_fast(RPF_F(-1.2684380046), RPF_F(2.6097574011), RPF_F(-0.3413193965), l3, m3, s3),
+                              dot3_fast(RPF_F(-0.0041960863), RPF_F(-0.7034186147), RPF_F(1.7076147010), l3, m3, s3)};
+        float out[3];
+        for (int k = 0; k < 3; ++k) {
+            const float c = lin[k];
+            const float hi = clamp01(__builtin_fmaf(chain_k_gamma_mul(T), powc_fast<POW_GAMMA>(c, T.gamma), -chain_k_gamma_off(T)));
             const float lo = clamp01(c * chain_k_gamma_lin(T));
             out[k] = c <= RPF_F(0.0031308) ? lo : hi;
         }

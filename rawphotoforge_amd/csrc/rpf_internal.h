@@ -16,6 +16,7 @@ struct rpf_processor {
     int variant = 0;
     rpf::MathTables* d_tabs = nullptr;
     rpf::LegacyTables* d_legacy = nullptr;  // Godot-legacy flavour only
+    rpf::FastTables* d_fast_tabs = nullptr; // RPF_PRECISION_FAST (rpf_fast.h), 17.5 KiB
     rpf::HueBound* d_hue_bounds = nullptr;  // 65536 entries, 1 MiB
     rpf::HueBoundCs* d_hue_cs = nullptr;    // 65536 entries, 2 MiB (HUE_DIRECT launches)
     // Arc<GpuProcessor> (lib.rs:83): one reference for the caller's handle plus one per editor created on it.
@@ -34,6 +35,7 @@ struct rpf_editor {
     bool owns_image = false;      // created from host pixels (vs. for_tile)
     bool is_bayer = false;
     int flavour = RPF_FLAVOUR_ACTIVE;
+    int precision = RPF_PRECISION_EXACT;
     rpf::RawParamsDev raw{};
     uint16_t* d_cfa = nullptr;    // (rows + 4) x width, rows 0,1 and rows+2,rows+3 are halo
     float* d_original = nullptr;  // RGBA32F linear (rgb editors; bayer editors: demosaic cache)

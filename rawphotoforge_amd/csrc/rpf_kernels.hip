@@ -67,6 +67,33 @@ __device__ __forceinline__ float chain_k_gamma_lin(const LdsTabs& T) { return T.
 __device__ __forceinline__ float chain_k_gamma_off(const LdsTabs& T) { return T.k_gamma_off; }
 __device__ __forceinline__ float chain_main_sat(const LdsTabs& T, const MaskParams&) { return T.main_sat; }
 __device__ __forceinline__ float chain_main_light(const LdsTabs& T, const MaskParams&) { return T.main_light; }
+// RPF_PRECISION_FAST: the binary32 tables of rpf_fast.h staged at LDS address `base` (in place of the MathTables), the same
+// launch-long constants, and the gamma's 1.055 (its affine step is one fma with the clamp modifier there: no literal)
+struct LdsFastTabs {
+    LdsFastPow cbrt, gamma;
+    float k_gamma_lin, k_gamma_off, k_gamma_mul, main_sat, main_light;
+    __device__ __forceinline__ LdsFastTabs(uint32_t base, const MaskParams& main)
+        : cbrt{base + (uint32_t)offsetof(FastTables, cbrt), FastPowCoef<POW_CBRT>::c3},
+          gamma{base + (uint32_t)offsetof(FastTables, gamma), FastPowCoef<POW_GAMMA>::c3},
+          k_gamma_lin(12.92f), k_gamma_off(0.055f), k_gamma_mul(1.055f), main_sat(main.sat_gain), main_light(main.light_gain)
+    {
+        asm volatile("" : "+v"(cbrt.c3), "+v"(gamma.c3), "+v"(k_gamma_lin), "+v"(k_gamma_off), "+v"(k_gamma_mul), "+v"(main_sat), "+v"(main_light));
+    }
+};
+__device__ __forceinline__ float chain_k_gamma_lin(const LdsFastTabs& T) { return T.k_gamma_lin; }
+__device__ __forceinline__ float chain_k_gamma_off(const LdsFastTabs& T) { return T.k_gamma_off; }
+__device__ __forceinline__ float chain_k_gamma_mul(const LdsFastTabs& T) { return T.k_gamma_mul; }
+__device__ __forceinline__ float chain_main_sat(const LdsFastTabs& T, const MaskParams&) { return T.main_sat; }
+__device__ __forceinline__ float chain_main_light(const LdsFastTabs& T, const MaskParams&) { return T.main_light; }
+template <int PREC> struct TabsOf { typedef LdsTabs type; static constexpr uint32_t BYTES = (uint32_t)sizeof(MathTables); };
+template <> struct TabsOf<1> { typedef LdsFastTabs type; static constexpr uint32_t BYTES = (uint32_t)sizeof(FastTables); };
+// the tables staged at the start of the dynamic shared block (LDS address 0)
+template <int PREC>
+__device__ __forceinline__ typename TabsOf<PREC>::type make_lds_tabs(const unsigned char* smem, const MaskParams& main)
+{
+    if constexpr (PREC == 1) return LdsFastTabs(0u, main);
+    else return LdsTabs(0u, reinterpret_cast<const MathTables*>(smem), main, true);
+}
 // Mask parameters as the multi-mask kernels read them: "main" through the kernel-argument segment (loaded once, scalar
 // registers), a user mask's 48 bytes from a copy in LDS at byte address `lds_base` with three 16-byte reads per mask per
 // step — wave-uniform values in vector registers, so the tone arithmetic also runs at the full f32 rate (an SGPR operand
@@ -351,6 +378,24 @@ __device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (
         edit_chain<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp, mainv}, ed.num_masks, luts, T);
     } else {
         edit_chain<2>(r, gg, b, active, ed.mp, ed.num_masks, luts, T);
+    }
+}
+
+// RPF_PRECISION_FAST: the same depths of specialisation over edit_chain_fast (rpf_chain.h)
+template <int MODE, class Luts>
+__device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (&b)[2], const uint32_t (&active)[2],
+                                          const DeviceEdit& ed, const Luts& luts, const LdsFastTabs& T, uint32_t lds_mp,
+                                          const MaskParams* mainv = nullptr)
+{
+    if (MODE == MODE_DEVELOP_1P) {
+        edit_chain_fast<2, (int)MF_PRISTINE>(r, gg, b, active, ed.mp, 1u, luts, T);
+    } else if (mode_single(MODE)) {
+        if (mainv) edit_chain_fast<2>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
+        else edit_chain_fast<2>(r, gg, b, active, ed.mp, 1u, luts, T);
+    } else if (MODE == MODE_DEVELOP_MP || MODE == MODE_DEVELOP_MPH) {
+        edit_chain_fast<2, (int)MF_PRISTINE>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
+    } else {
+        edit_chain_fast<2>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp, mainv}, ed.num_masks, luts, T);
     }
 }
 
@@ -696,10 +741,10 @@ __device__ __forceinline__ HpRow hp_row_taps(float a, float b, float ha, float h
 
 // The two pixels (columns 2l, 2l + 1 of the strip) of output row `row` through vignette, edit chain and the stores.
 // colF: the column whose pixel this lane stores from the first register after the half-wave swap (second: + 64).
-template <int MODE, bool LDS_LUT, int OUTFMT, bool VIGN>
+template <int MODE, bool LDS_LUT, int OUTFMT, bool VIGN, class Tabs>
 __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (&b)[2], int row, const int (&col)[2],
                                           int colF, const TileGeom& g, const DeviceEdit& ed, const DevLuts<LDS_LUT>& luts,
-                                          const LdsTabs& T, void* out, const float (&fall)[2], uint32_t lds_mp,
+                                          const Tabs& T, void* out, const float (&fall)[2], uint32_t lds_mp,
                                           uint32_t dead_lo, uint32_t dead_hi, const uint32_t (&alpha)[2], const MaskParams* mainv)
 {
     const int W = (int)g.width, rows = (int)g.rows;
@@ -737,23 +782,27 @@ __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (
     store_px_buf<OUTFMT>(rs, offF + 64u * BPP, bits2f(sr[1]), bits2f(sg[1]), bits2f(sb[1]), alpha[1]);
 }
 
-template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool VIGN = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1)))
+// PREC: 0 = every builtin correctly rounded (rpf_math.h; the default and the parity gate), 1 = RPF_PRECISION_FAST (rpf_fast.h)
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, bool VIGN = false, int PREC = 0>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? (PREC ? 5 : 4) : 1)))
 void k_hp(const StreamArgs a)
 {
     static_assert(MODE != MODE_DEMOSAIC, "the demosaic-only kernel is store-bound: k_stream");
     extern __shared__ __align__(16) unsigned char smem[];
-    MathTables* T = reinterpret_cast<MathTables*>(smem);
-    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
+    constexpr uint32_t TAB_BYTES = TabsOf<PREC>::BYTES;
+    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + TAB_BYTES);
     const int tid = threadIdx.x;
-    constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
+    constexpr uint32_t LDS_MP = TAB_BYTES + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     constexpr bool MULTI = mode_multi(MODE);
     assert_lds_base(smem);
-    stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
+    stage16<NT, (int)(TAB_BYTES / 16)>(PREC ? reinterpret_cast<const uint4*>(a.ed.fast_tabs) : reinterpret_cast<const uint4*>(a.ed.tabs),
+                                       reinterpret_cast<uint4*>(smem), tid);
+    if (LDS_LUT)
+        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright), reinterpret_cast<uint4*>(lut), tid);
     if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();  // the only barrier of the kernel
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
-    const LdsTabs tabs(0u, T, a.ed.mp[0], true);
+    const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC>(smem, a.ed.mp[0]);
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
     // the tile's vignette falloff map: rows x W binary32 (run_hp checks that it exists and is shorter than 4 GiB)
@@ -1582,7 +1631,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
 }
 
 // k_hp's launcher: 128-column strips that start on an R column, steps that start on an R row (see the kernel).
-template <int NT, int MODE, bool LDS_LUT, int OUTFMT>
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, int PREC = 0>
 static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                          const DeviceEdit* ed, void* d_out, hipStream_t s)
 {
@@ -1595,17 +1644,19 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
     const uint32_t total_pairs = (g.rows + bp + 1) / 2;
     a.strips = (g.width + (uint32_t)raw.xo + HP_STRIP_W - 1) / HP_STRIP_W;
     constexpr uint32_t WPB = NT / 64;
-    const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
+    const size_t lds = TabsOf<PREC>::BYTES + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
                        (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
     const bool vign = ed->vign_strength != 0.0f;
+    if (PREC && !ed->fast_tabs) return hipErrorInvalidValue;
     // k_hp reads the vignette's falloff from the tile's map (the API layer builds it when the slider leaves 0)
     if (vign && (!ed->vign_falloff || (uint64_t)g.rows * g.width * 4u > 0xffffffffull)) return hipErrorInvalidValue;
-    auto kernel = vign ? k_hp<NT, MODE, LDS_LUT, OUTFMT, true> : k_hp<NT, MODE, LDS_LUT, OUTFMT, false>;
+    auto kernel = vign ? k_hp<NT, MODE, LDS_LUT, OUTFMT, true, PREC> : k_hp<NT, MODE, LDS_LUT, OUTFMT, false, PREC>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     // persistent workgroups, as many as are resident: four 256-thread workgroups per CU (about 110 VGPRs: four waves per
     // SIMD), one 1024-thread workgroup where the 128-KiB curve is staged in LDS
     uint32_t per_cu = LDS_LUT ? 1u : (uint32_t)(1024 / NT);
+    if (PREC && NT == 256 && cfg.variant == 30) per_cu = 5;  // A/B: the binary32 kernel needs < 96 VGPRs, five waves per SIMD fit
     {
         static std::atomic<int> resident[2];
         int nb = resident[vign].load(std::memory_order_relaxed);
@@ -1727,6 +1778,17 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     // five waves per SIMD (k_stream: 93 VGPRs) hide that better than four (4 masks 0.324 vs 0.345 ms, 8 masks 0.467 vs
     // 0.538: profiles/r03_experiments.md); variant 21 (A/B) forces k_hp there too
     const bool hp = (hp_variant && ed.num_masks == 1) || cfg.variant == 21;
+    // RPF_PRECISION_FAST (rpf_fast.h, edit_chain_fast): a specialisation of k_hp for launches with only "main" — pristine
+    // (set D) or with run-time flags and curves.  Every other launch computes the exact chain, which meets the fast
+    // mode's tolerances trivially.
+    if (ed.precision == 1u && ed.num_masks == 1 && (cfg.variant == 0 || cfg.variant == 30 || cfg.variant == 31) &&
+        !(ed.vign_strength != 0.0f && !ed.vign_falloff)) {
+        if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 0)  // A/B (30: five, 31: four 256-thread workgroups per CU)
+            return run_hp<256, MODE_DEVELOP_1P, false, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
+        if (ed.mp[0].flags == MF_PRISTINE) return run_hp<1024, MODE_DEVELOP_1P, false, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
+        return lut ? run_hp<1024, MODE_DEVELOP_1, true, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s)
+                   : run_hp<1024, MODE_DEVELOP_1, false, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    }
     if (ed.num_masks == 1 && cfg.variant != 7) {  // variant 7 (A/B): the general kernel on a single mask
         if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12)  // variant 12 (A/B): run-time flags also for a pristine "main"
             return run_fused<256, MODE_DEVELOP_1P, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);

@@ -33,6 +33,10 @@ struct DeviceEdit {
     // Godot-legacy shader flavour (k_apply only): EF_* bits, and the c = 2.4 table when EF_DECODE_INPUT is set
     uint32_t flags;
     const LegacyTables* legacy;
+    // rpf_set_precision: 0 = every builtin correctly rounded (the default), 1 = RPF_PRECISION_FAST — launches that have a
+    // binary32-only specialisation (rpf_fast.h) take it and read these tables instead of `tabs`
+    uint32_t precision;
+    const FastTables* fast_tabs;
 };
 enum EditFlags : uint32_t { EF_LEGACY_VIGNETTE = 1u, EF_DECODE_INPUT = 2u };
 

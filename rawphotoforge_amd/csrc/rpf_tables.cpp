@@ -1,6 +1,6 @@
 // rpf_tables.cpp — host-side construction of the MathTables the kernels stage in LDS.
 // Long-double (x87, 64-bit significand) evaluation, rounded once to binary64.
-#include "rpf_math.h"
+#include "rpf_fast.h"
 
 #include <math.h>
 
@@ -80,6 +80,34 @@ void build_hue_bounds(HueBound* B, HueBoundCs* Cs, const MathTables& T)
         Cs[j].c = B[j].c;
         Cs[j].s = B[j].s;
     }
+}
+
+// rpf_fast.h: entry (e, j) = { r = 2^-e r0, r0 ~ 1 / bin centre on a 2^-12 grid, T = RN(V), rho = RN((V - T) / T) }, V = 2^(e c) r0^(-c)
+template <int KIND>
+static void build_fast_pow(FastPowEntry* tab, float cf)
+{
+    using G = FastPowGeom<KIND>;
+    const long double c = (long double)cf;
+    for (int row = 0; row < G::ROWS; ++row) {
+        const int e = G::E0 + row;
+        for (int j = 0; j < FAST_POW_J; ++j) {
+            FastPowEntry& o = tab[row * FAST_POW_J + j];
+            const long double mid = 1.0L + ((long double)j + 0.5L) / (long double)FAST_POW_J;
+            const long double r0 = roundl((1.0L / mid) * 4096.0L) / 4096.0L;
+            o.r = (float)ldexpl(r0, -e);  // exact: twelve significant bits
+            const long double V = powl(2.0L, (long double)e * c) * powl(r0, -c);
+            o.T = (float)V;
+            o.rho = (float)((V - (long double)o.T) / (long double)o.T);
+            o.pad = 0.0f;
+            if (KIND == POW_CBRT && row == 0) o.r = o.T = o.rho = 0.0f;  // everything below 2^-21 (and 0) -> 0
+        }
+    }
+}
+
+void build_fast_tables(FastTables& T)
+{
+    build_fast_pow<POW_CBRT>(T.cbrt, (float)(1.0 / 3.0));    // wgsl:67
+    build_fast_pow<POW_GAMMA>(T.gamma, (float)(1.0 / 2.4));  // wgsl:98
 }
 
 void build_legacy_tables(LegacyTables& T)

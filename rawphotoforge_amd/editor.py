@@ -332,6 +332,17 @@ class PhotoEditor:
         sRGB-encoded input linearised in the kernel, the older vignette)."""
         _check(N.lib().rpf_set_shader_flavour(self._h, flavour))
 
+    def set_precision(self, precision: int) -> None:
+        """PRECISION_EXACT (default: every builtin correctly rounded, bit-identical to the parity oracle) or PRECISION_FAST
+        (binary32-only builtins within 1 ulp, contracted matrix products; include/rpf.h rpf_set_precision)."""
+        _check(N.lib().rpf_set_precision(self._h, precision))
+
+    @property
+    def precision(self) -> int:
+        v = C.c_int(0)
+        _check(N.lib().rpf_get_precision(self._h, C.byref(v)))
+        return v.value
+
     @property
     def num_masks(self) -> int:
         v = C.c_uint32(0)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../rawphotoforge_amd/csrc/rpf_fast.h"
 #include "../../rawphotoforge_amd/csrc/rpf_math.h"
 
 // sqrt_cr(s) against the compiler's IEEE expansion of sqrtf for the bit patterns [lo, lo + n)
@@ -148,5 +149,99 @@ extern "C" int gpu_hue_candidate_sweep(uint32_t lo_bits, uint64_t n, float* max_
     (void)hipMemcpy(&bits, d, 4, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     *max_err = rpf::bits2f(bits);
+    return rc;
+}
+
+
+// ---- RPF_PRECISION_FAST builtins (rpf_fast.h) on the device ----------------------------------------------------------
+
+// v_sqrt_f32 against the IEEE square root: the largest distance in ulp over the bit patterns [lo, lo + n) (positive normals)
+__global__ void k_fast_sqrt_sweep(uint32_t lo, uint64_t n, unsigned int* max_ulp)
+{
+    unsigned int worst = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float s = rpf::bits2f(lo + (uint32_t)i);
+        const float got = rpf::sqrt_fast(s);
+        volatile float sv = s;
+        const float ref = __builtin_sqrtf(sv);
+        const int d = (int)rpf::f2bits(got) - (int)rpf::f2bits(ref);  // both positive: patterns order like values
+        const unsigned int a = (unsigned int)(d < 0 ? -d : d);
+        worst = a > worst ? a : worst;
+    }
+    atomicMax(max_ulp, worst);
+}
+
+extern "C" int gpu_fast_sqrt_sweep(uint32_t lo_bits, uint64_t n, uint32_t* max_ulp)
+{
+    unsigned int* d = nullptr;
+    if (hipMalloc((void**)&d, 4) != hipSuccess) return 1;
+    (void)hipMemset(d, 0, 4);
+    hipLaunchKernelGGL(k_fast_sqrt_sweep, dim3(256 * 8), dim3(256), 0, 0, lo_bits, n, d);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    (void)hipMemcpy(max_ulp, d, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return rc;
+}
+
+// hue_position_fast on the device (v_rcp_f32 inside) for n directions
+__global__ void k_fast_hue_position(const float* y, const float* x, uint64_t n, float* out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = rpf::hue_position_fast(y[i], x[i]);
+}
+
+extern "C" int gpu_fast_hue_position(const float* y, const float* x, uint64_t n, float* out)
+{
+    float *dy = nullptr, *dx = nullptr, *dout = nullptr;
+    if (hipMalloc((void**)&dy, n * 4) != hipSuccess || hipMalloc((void**)&dx, n * 4) != hipSuccess ||
+        hipMalloc((void**)&dout, n * 4) != hipSuccess)
+        return 1;
+    (void)hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_fast_hue_position, dim3(2048), dim3(256), 0, 0, dy, dx, n, dout);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    (void)hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout);
+    return rc;
+}
+
+// powc_fast (which: 0 = cube root, 1 = gamma) over the bit patterns [lo, lo + n) with the table the host built, and
+// sincos_hue_fast for all 65536 indices: IEEE operations only, so these must be the host twin's bits
+__global__ void k_fast_pow_range(int which, uint32_t lo, uint64_t n, const rpf::FastTables* T, float* out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = rpf::bits2f(lo + (uint32_t)i);
+        out[i] = which == 0 ? rpf::powc_fast<rpf::POW_CBRT>(x, &T->cbrt[0]) : rpf::powc_fast<rpf::POW_GAMMA>(x, &T->gamma[0]);
+    }
+}
+
+extern "C" int gpu_fast_pow_range(int which, uint32_t lo_bits, uint64_t n, const void* host_tables, float* out)
+{
+    rpf::FastTables* dT = nullptr;
+    float* dout = nullptr;
+    if (hipMalloc((void**)&dT, sizeof(rpf::FastTables)) != hipSuccess || hipMalloc((void**)&dout, n * 4) != hipSuccess) return 1;
+    (void)hipMemcpy(dT, host_tables, sizeof(rpf::FastTables), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_fast_pow_range, dim3(2048), dim3(256), 0, 0, which, lo_bits, n, dT, dout);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    (void)hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dT); (void)hipFree(dout);
+    return rc;
+}
+
+__global__ void k_fast_sincos_all(float* cs, float* sn)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    rpf::sincos_hue_fast((float)k, cs[k], sn[k]);
+}
+
+extern "C" int gpu_fast_sincos_all(float* cs, float* sn)
+{
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, 2 * 65536 * 4) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_fast_sincos_all, dim3(256), dim3(256), 0, 0, d, d + 65536);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    (void)hipMemcpy(cs, d, 65536 * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(sn, d + 65536, 65536 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
     return rc;
 }

@@ -1,0 +1,204 @@
+"""RPF_PRECISION_FAST on the GPU (run on the GPU box: -m gpu): the binary32-only builtins as the device evaluates them, and
+the fast specialisation of the fused kernel against the oracle / the exact kernel: ULP histogram, distance, index-flip rate.
+The exact kernel stays the parity gate (tests/test_gpu_parity.py); what is asserted here are the bounds include/rpf.h states
+for rpf_set_precision."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import rawphotoforge_amd as R
+from rawphotoforge_amd import synthetic as syn
+from tests import util
+from tests.util import build_checker
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(util.GOLDEN, "chain_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def checker(gpu):   # after the product library has initialised the device (its processor exists)
+    lib = C.CDLL(build_checker())
+    lib.gpu_fast_sqrt_sweep.restype = C.c_int
+    lib.gpu_fast_sqrt_sweep.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.gpu_fast_hue_position.restype = C.c_int
+    lib.gpu_fast_hue_position.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.gpu_fast_pow_range.restype = C.c_int
+    lib.gpu_fast_pow_range.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.gpu_fast_sincos_all.restype = C.c_int
+    lib.gpu_fast_sincos_all.argtypes = [C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- the builtins ------------------------------------------------------------------------------------------------
+def test_fast_sqrt_within_one_ulp_on_every_positive_normal(checker):
+    """v_sqrt_f32 against the IEEE square root on every positive normal binary32 (the chain's argument a^2 + b^2 is 0 or
+    a normal number below 64)."""
+    worst = 0
+    for lo in range(0x00800000, 0x7f800000, 1 << 28):
+        n = min(1 << 28, 0x7f800000 - lo)
+        m = C.c_uint32(0)
+        assert checker.gpu_fast_sqrt_sweep(lo, n, C.byref(m)) == 0
+        worst = max(worst, m.value)
+    assert worst <= 1, worst
+
+
+def test_fast_pows_and_sincos_on_the_device_are_the_host_twin_bit_for_bit(checker):
+    """powc_fast and sincos_hue_fast are IEEE operations only: the device must produce the bits tests/test_fast_math.py
+    checks against the oracle on the CPU (every binary32 of two binades per table here, and all 65536 hue indices)."""
+    tw = util.twin()
+    tw.twin_fast_tables.restype = C.c_size_t
+    size = tw.twin_fast_tables(None, C.c_size_t(0))
+    tabs = np.empty(size, np.uint8)
+    tw.twin_fast_tables(_P(tabs), C.c_size_t(size))
+    for which, lo in ((0, 0x3f000000), (0, 0x3a000000), (1, 0x3f000000), (1, 0x3b800000)):   # [0.5, 1), [2^-11, 2^-10), ..
+        n = 1 << 23
+        dev, host = np.empty(n, np.float32), np.empty(n, np.float32)
+        assert checker.gpu_fast_pow_range(which, lo, n, _P(tabs), _P(dev)) == 0
+        tw.twin_fast_pow_range(C.c_int(which), C.c_uint32(lo), C.c_uint32(n), _P(host))
+        assert np.array_equal(dev.view(np.uint32), host.view(np.uint32)), (which, hex(lo))
+    dc, ds, hc, hs = (np.empty(65536, np.float32) for _ in range(4))
+    assert checker.gpu_fast_sincos_all(_P(dc), _P(ds)) == 0
+    tw.twin_fast_sincos_all(_P(hc), _P(hs))
+    assert np.array_equal(dc.view(np.uint32), hc.view(np.uint32)) and np.array_equal(ds.view(np.uint32), hs.view(np.uint32))
+
+
+def test_fast_hue_index_on_the_device(checker):
+    """hue_position_fast with the hardware reciprocal: the oracle's index or its neighbour, flip rate below 0.2 %."""
+    orc = O.lib()
+    rng = np.random.default_rng(6)
+    n = 4_000_000
+    th, rad = rng.uniform(0, 2 * np.pi, n), 10.0 ** rng.uniform(-4, 0, n)
+    x, y = (rad * np.cos(th)).astype(np.float32), (rad * np.sin(th)).astype(np.float32)
+    v, k = np.empty(n, np.float32), np.empty(n, np.uint32)
+    assert checker.gpu_fast_hue_position(_P(y), _P(x), n, _P(v)) == 0
+    orc.orc_hue_index_many(_P(y), _P(x), C.c_size_t(n), _P(k))
+    assert v.min() >= 0.0 and v.max() <= 65535.0
+    d = np.trunc(v).astype(np.int64) - k.astype(np.int64)
+    d = np.where(d > 32768, d - 65536, np.where(d < -32768, d + 65536, d))
+    assert np.abs(d).max() <= 1
+    assert (d != 0).mean() < 0.002, (d != 0).mean()
+
+
+# ---- the kernel --------------------------------------------------------------------------------------------------
+def _stats(got, want):
+    got = np.asarray(got, np.float32).reshape(want.shape)[..., :3]
+    want = want[..., :3]
+    ulp = util.ulp_diff(got, want)
+    ad = np.abs(got.astype(np.float64) - want.astype(np.float64)).reshape(-1, 3).max(1)
+    return ulp, ad
+
+
+def _assert_fast_bounds(got, want, what, flip_bound=4e-3):
+    """Median 1 ulp per channel; at least 99 % of the pixels within 1e-5; the others are hue-index flips: the hue moves by
+    one step of the index scale, which with smooth or trivial OKLCH curves stays below `flip_bound` (the gamma's slope at
+    dark values times 1 / 65535 of a turn of a saturated colour) — a steep hue / saturation / lightness curve scales it."""
+    ulp, ad = _stats(got, want)
+    assert np.median(ulp) <= 1, (what, float(np.median(ulp)))
+    assert (ad <= 1e-5).mean() >= 0.99, (what, float((ad <= 1e-5).mean()))
+    assert ad.max() <= flip_bound, (what, float(ad.max()))
+    assert np.array_equal(np.asarray(got, np.float32).reshape(want.shape)[..., 3], want[..., 3])  # alpha = 1
+
+
+@pytest.mark.parametrize("pname", ["D", "S"])
+@pytest.mark.parametrize("tag", ["U", "N"])
+def test_fast_develop_against_the_committed_golden(gpu, tag, pname):
+    """The committed 64x64 frames: the fast kernel within its bounds of the golden output, and the same editor switched
+    back to EXACT reproduces the golden bit for bit (the precision is a per-launch choice, no state is left behind)."""
+    cfa = GOLD[f"cfa64_{tag}"]
+    p = util.params_D() if pname == "D" else util.params_S()
+    ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(util.raw_params()))
+    util.configure_editor(ed, p)
+    ed.set_precision(R.PRECISION_FAST)
+    assert ed.precision == R.PRECISION_FAST
+    ed.apply_adjustments()
+    want = GOLD[f"develop64_{tag}_{pname}"]
+    _assert_fast_bounds(ed.rgba(), want, (tag, pname))
+    ed.set_precision(R.PRECISION_EXACT)
+    ed.apply_adjustments()
+    assert np.array_equal(np.asarray(ed.rgba(), np.float32).reshape(want.shape).view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("pname", ["D", "S", "G", "V", "T"])
+def test_fast_develop_256_against_the_oracle(gpu, pname):
+    """256x256 natural-like and uniform frames, five edit sets (pristine / stress with the brightness curve in LDS and the
+    vignette map / all four curves / vignette only / tone sliders), ragged sizes included: bounds against the oracle."""
+    for shape, maker in (((256, 256), util.bayer_natural), ((130, 301), util.bayer_uniform)):
+        cfa = maker(*shape)
+        rp = util.raw_params()
+        p = util.oracle_params(syn.PARAM_SETS[pname])
+        ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+        util.configure_editor(ed, p)
+        ed.set_precision(R.PRECISION_FAST)
+        ed.apply_adjustments()
+        _assert_fast_bounds(ed.rgba(), O.develop(cfa, rp, [p]), (pname, shape), flip_bound=3e-2 if pname == "G" else 4e-3)
+
+
+def test_fast_develop_every_cfa_layout_and_output_format(gpu):
+    cfa = util.bayer_uniform(96, 200, seed=9)
+    for pat in (O.CFA_RGGB, O.CFA_BGGR, O.CFA_GRBG, O.CFA_GBRG):
+        rp = util.raw_params(pat)
+        ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+        ed.set_precision(R.PRECISION_FAST)
+        ed.apply_adjustments()
+        want = O.develop(cfa, rp, [util.params_D()])
+        _assert_fast_bounds(ed.rgba(), want, pat)
+        rgb = np.asarray(ed.to_flat_vec_rgb(), np.float32).reshape(96, 200, 3)
+        assert np.array_equal(rgb, np.asarray(ed.rgba(), np.float32).reshape(96, 200, 4)[..., :3])
+
+
+def test_fast_falls_back_to_the_exact_chain_where_it_has_no_specialisation(gpu):
+    """User masks: no binary32 specialisation — the launch computes the exact chain (bit-identical to the oracle)."""
+    cfa = util.bayer_natural(64, 96)
+    rp = util.raw_params()
+    ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+    m = np.zeros((64, 96), np.float32)
+    m[:, 40:] = 1.0
+    ed.add_mask("right", m)
+    ps = util.params_S()
+    ps.vignette = 0
+    util.configure_editor(ed, ps, mask_name="right", main=False)
+    ed.set_precision(R.PRECISION_FAST)
+    ed.apply_adjustments()
+    want = O.develop(cfa, rp, [util.params_D(), ps], masks=np.stack([m]))
+    assert np.array_equal(np.asarray(ed.rgba(), np.float32).reshape(want.shape).view(np.uint32), want.view(np.uint32))
+
+
+def test_fast_develop_full_frame_statistics(gpu):
+    """BASELINE's 6000x4000 frame, set D: the fast kernel against the exact kernel of the same build (which
+    tests/test_gpu_parity.py pins to the oracle on this geometry): ULP histogram, distance and hue-flip share."""
+    import torch
+    from rawphotoforge_amd import tiles
+    H, W = 4000, 6000
+    cfa = syn.bayer_uniform(H, W, seed=20260630)
+    rp = util.to_raw(util.raw_params())
+    dev = torch.device("cuda:0")
+    band = torch.zeros((H + 4, W), dtype=torch.int16, device=dev)
+    band[2:H + 2] = torch.from_numpy(cfa.view(np.int16)).to(dev)
+    ed = R.PhotoEditor.for_tile(gpu, W, H, 0, H)
+    outs = []
+    for prec in (R.PRECISION_EXACT, R.PRECISION_FAST):
+        ed.set_precision(prec)
+        out = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        ed.dev_develop(band.data_ptr(), rp, out.data_ptr(), R.OUT_RGBA_F32, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(out)
+    exact, fast = outs
+    d = (fast[..., :3] - exact[..., :3]).abs().amax(dim=2)
+    n = d.numel()
+    within = float((d <= 1e-5).sum()) / n
+    assert within >= 0.99, within
+    assert float(d.max()) <= 4e-3
+    same = float((d == 0).sum()) / n
+    assert same > 0.05      # a fair share of the pixels is bit-identical
+    ei, fi = exact[..., :3].contiguous().view(torch.int32), fast[..., :3].contiguous().view(torch.int32)
+    ulp = (ei - fi).abs()
+    assert float(ulp.float().median()) <= 1
+    assert torch.equal(fast[..., 3], exact[..., 3])

@@ -13,6 +13,7 @@ namespace rpf {
 void build_math_tables(MathTables& T);
 void build_legacy_tables(LegacyTables& T);
 void build_hue_bounds(HueBound* B, HueBoundCs* Cs, const MathTables& T);
+void build_fast_tables(FastTables& T);
 }
 
 // function-local statics: initialised once, thread-safely (several loops below run under OpenMP)
@@ -31,6 +32,16 @@ static const rpf::LegacyTables& legacy_tabs()
     static const rpf::LegacyTables* t = [] {
         rpf::LegacyTables* m = new rpf::LegacyTables;
         rpf::build_legacy_tables(*m);
+        return m;
+    }();
+    return *t;
+}
+
+static const rpf::FastTables& fast_tabs()
+{
+    static const rpf::FastTables* t = [] {
+        rpf::FastTables* m = new rpf::FastTables;
+        rpf::build_fast_tables(*m);
         return m;
     }();
     return *t;
@@ -144,6 +155,33 @@ void twin_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
     }
 }
 
+// ---- RPF_PRECISION_FAST builtins (rpf_fast.h) --------------------------------------------------
+float twin_fast_pow_cbrt(float x) { return rpf::powc_fast<rpf::POW_CBRT>(x, fast_tabs().cbrt); }
+float twin_fast_pow_gamma(float x) { return rpf::powc_fast<rpf::POW_GAMMA>(x, fast_tabs().gamma); }
+void twin_fast_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
+{
+    const rpf::FastTables& T = fast_tabs();
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) {
+        const float x = rpf::bits2f(bits_lo + (uint32_t)i);
+        out[i] = which == 0 ? rpf::powc_fast<rpf::POW_CBRT>(x, T.cbrt) : rpf::powc_fast<rpf::POW_GAMMA>(x, T.gamma);
+    }
+}
+size_t twin_fast_tables(void* out, size_t cap)  // the FastTables as the product builds them (for the on-device checks)
+{
+    if (cap >= sizeof(rpf::FastTables)) memcpy(out, &fast_tabs(), sizeof(rpf::FastTables));
+    return sizeof(rpf::FastTables);
+}
+void twin_fast_sincos_all(float* cs, float* sn)  // 65536 each
+{
+    for (uint32_t k = 0; k < 65536; ++k) rpf::sincos_hue_fast((float)k, cs[k], sn[k]);
+}
+void twin_fast_hue_position_many(const float* y, const float* x, size_t n, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) out[i] = rpf::hue_position_fast(y[i], x[i]);
+}
+
 // whole edit chain on npix pixels (rgb in, rgba out), masks all-ones
 void twin_edit_chain(const float* rgb, size_t npix, const rpf::MaskParams* mp, uint32_t num_masks,
                      const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
@@ -183,6 +221,28 @@ void twin_edit_chain_fused(const float* rgb, size_t npix, const rpf::MaskParams*
     }
 }
 
+// RPF_PRECISION_FAST: edit_chain_fast with the host forms of its builtins (the device's pows, sine and cosine bit for bit;
+// its square root and the reciprocal inside the hue position are hardware approximations there, IEEE operations here)
+struct HostFastTabs {
+    const rpf::FastPowEntry* cbrt;
+    const rpf::FastPowEntry* gamma;
+};
+void twin_edit_chain_fast(const float* rgb, size_t npix, const rpf::MaskParams* mp, uint32_t num_masks,
+                          const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
+                          float* rgba_out)
+{
+    HostLuts L{bright, hue, sat, light};
+    const HostFastTabs T{fast_tabs().cbrt, fast_tabs().gamma};
+    const uint32_t active = num_masks >= 32 ? 0xffffffffu : ((1u << num_masks) - 1u);
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)npix; ++i) {
+        float r[1] = {rgb[i * 3]}, g[1] = {rgb[i * 3 + 1]}, b[1] = {rgb[i * 3 + 2]};
+        const uint32_t act[1] = {active};
+        rpf::edit_chain_fast<1>(r, g, b, act, mp, num_masks, L, T);
+        rgba_out[i * 4] = r[0]; rgba_out[i * 4 + 1] = g[0]; rgba_out[i * 4 + 2] = b[0]; rgba_out[i * 4 + 3] = 1.0f;
+    }
+}
+
 size_t twin_sizeof_mask_params(void) { return sizeof(rpf::MaskParams); }
 }
 
@@ -201,7 +261,7 @@ struct twin_edit_params {  // same layout as oracle's orc_edit_params
 // host code) + edit_chain (the kernels' arithmetic) on the CPU.
 void twin_apply_mode(const float* rgb, size_t npix, const twin_edit_params* ep, uint32_t num_masks,
                      const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
-                     float* rgba_out, int fused)   // fused != 0 (num_masks == 1): through the fused hue table
+                     float* rgba_out, int fused)   // 1 (num_masks == 1): through the fused hue table; 2: RPF_PRECISION_FAST
 {
     std::vector<rpf::MaskParams> mp(num_masks);
     for (uint32_t m = 0; m < num_masks; ++m) {
@@ -214,7 +274,8 @@ void twin_apply_mode(const float* rgb, size_t npix, const twin_edit_params* ep, 
             p.curve[c].assign(src[c] + (size_t)m * RPF_CURVE_RESOLUTION, src[c] + (size_t)(m + 1) * RPF_CURVE_RESOLUTION);
         mp[m] = rpf::make_mask_params(p);
     }
-    if (fused) twin_edit_chain_fused(rgb, npix, mp.data(), bright, hue, sat, light, rgba_out);
+    if (fused == 2) twin_edit_chain_fast(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
+    else if (fused) twin_edit_chain_fused(rgb, npix, mp.data(), bright, hue, sat, light, rgba_out);
     else twin_edit_chain(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
 }
 

@@ -18,7 +18,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def build_twin(force=False) -> str:
     deps = [TWIN_SRC] + [os.path.join(ROOT, "rawphotoforge_amd", "csrc", f)
-                         for f in ("rpf_math.h", "rpf_chain.h", "rpf_host.h", "rpf_tables.cpp")]
+                         for f in ("rpf_math.h", "rpf_fast.h", "rpf_chain.h", "rpf_host.h", "rpf_tables.cpp")]
     if not force and os.path.exists(TWIN_LIB) and all(os.path.getmtime(TWIN_LIB) >= os.path.getmtime(d) for d in deps):
         return TWIN_LIB
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared",
@@ -32,11 +32,12 @@ def build_twin(force=False) -> str:
 CHECKER_SRC = os.path.join(ROOT, "tests", "gpu_math", "gpu_math_check.hip")
 CHECKER_LIB = os.path.join(ROOT, "tests", "gpu_math", "librpf_gpu_math_check.so")
 CHECKER_HDR = os.path.join(ROOT, "rawphotoforge_amd", "csrc", "rpf_math.h")
+CHECKER_HDR2 = os.path.join(ROOT, "rawphotoforge_amd", "csrc", "rpf_fast.h")
 
 
 def build_checker(force=False) -> str:
     if force or not os.path.exists(CHECKER_LIB) or os.path.getmtime(CHECKER_LIB) < max(os.path.getmtime(CHECKER_SRC),
-                                                                                      os.path.getmtime(CHECKER_HDR)):
+                                                                                      os.path.getmtime(CHECKER_HDR), os.path.getmtime(CHECKER_HDR2)):
         subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--offload-arch=gfx950", "-O3",
                         "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", CHECKER_SRC, "-o", CHECKER_LIB], check=True)
     return CHECKER_LIB
@@ -66,10 +67,11 @@ def twin():
     return _twin
 
 
-def twin_apply(rgb, masks_params, fused=False) -> np.ndarray:
+def twin_apply(rgb, masks_params, fused=False, fast=False) -> np.ndarray:
     """Device arithmetic (rpf_chain.h) + the product's host parameter packing, on the CPU.  fused=True (one mask): the
     chain as the fused develop kernels run it when the mask's hue / saturation / lightness curves are folded into the
-    fused hue table (edit_chain's HUE_MODE 2)."""
+    fused hue table (edit_chain's HUE_MODE 2).  fast=True: edit_chain_fast (RPF_PRECISION_FAST) with the host forms of
+    its builtins."""
     n = len(masks_params)
     a = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
     ep = (O.EditParamsC * n)(*[p.to_c() for p in masks_params])
@@ -77,7 +79,8 @@ def twin_apply(rgb, masks_params, fused=False) -> np.ndarray:
             for nm in ("brightness_tone_curve", "hue_tone_curve", "saturation_tone_curve", "lightness_tone_curve")]
     out = np.empty((a.shape[0], 4), np.float32)
     twin().twin_apply_mode(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.shape[0]), ep, C.c_uint32(n),
-                           *[l.ctypes.data_as(C.c_void_p) for l in luts], out.ctypes.data_as(C.c_void_p), C.c_int(1 if fused else 0))
+                           *[l.ctypes.data_as(C.c_void_p) for l in luts], out.ctypes.data_as(C.c_void_p),
+                           C.c_int(2 if fast else (1 if fused else 0)))
     return out
 
 

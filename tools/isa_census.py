@@ -70,10 +70,11 @@ def innermost_loop(body):
     if not headers:
         raise SystemExit("no loop found")
     depth = max(d for _, d in headers)
-    # the longest loop of that depth (the step loop; the prologue may hold short waterfall loops)
+    # the longest loop below the item loop (depth 1): the step loop — the prologue may hold short waterfall loops, and the
+    # progress-priority bookkeeping a two-instruction loop of its own inside the step loop
     best = None
     for i, d in headers:
-        if d != depth:
+        if d != depth and not (depth > 2 and d == depth - 1):
             continue
         while not body[i].startswith(".LBB"):  # the comment may continue below the label's own line
             i -= 1
