@@ -93,7 +93,9 @@ def main():
                          "share nothing — two RCCL communicators (two rpf_shards), two streams, two band buffers, each shard's own "
                          "thread enqueuing its steps (rpf_shard_develop_async), frames alternating between them: one frame's "
                          "exchange and launch latency run beside the other frame's kernel without a cross-stream dependency.  "
-                         "auto = pingpong when the library's communicators exist, else serial")
+                         "auto (default) = serial for the headline line — the one schedule whose every ordering is a stream order — and, "
+                         "when the library's two communicators exist, the same K steps again as pingpong, reported under "
+                         "secondary.pingpong (a stall there ends at the library's deadline with the serial line intact)")
     ap.add_argument("--pack", default="msb", choices=["msb", "mipi"],
                     help="develop_packed: 14-bit MSB-first bit stream (default) or MIPI CSI-2 RAW14 groups")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -228,8 +230,9 @@ def main():
             raise SystemExit("--halo once: a fused develop workload, no --schedule")
         schedule = "serial"
     lib_sched_ok = sharded and shard is not None and args.workload in ("develop", "develop_packed")
+    also_pingpong = schedule == "auto" and lib_sched_ok and shard_b is not None and not halo_once
     if schedule == "auto":
-        schedule = "pingpong" if (lib_sched_ok and shard_b is not None) else "serial"
+        schedule = "serial"
     if schedule in ("ahead", "pingpong") and not lib_sched_ok:
         raise SystemExit(f"--schedule {schedule} needs the library's communicator (N > 1, --exchange rccl) and a fused develop workload")
     args.overlap = schedule == "overlap"
@@ -349,7 +352,7 @@ def main():
         torch.cuda.synchronize()
 
     pp_devs = pp_bands = pp_outs = pp_streams = None
-    if schedule == "pingpong":
+    if schedule == "pingpong" or also_pingpong:
         if args.workload == "develop":
             pp_devs = (dev, make_developer(configure, lane_shard=shard_b))
             pp_bands = (band, band.clone())
@@ -361,10 +364,15 @@ def main():
         # kernels sharing the CUs: 37 instead of 25 us per step on a 6000x500 band); a priority makes that state unstable
         pp_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0))
 
-    def drain():   # pingpong: the shards' threads have enqueued everything handed to them; then the device
-        if schedule == "pingpong":   # (flush FIRST: a device-wide synchronise while the threads are still enqueuing is slow)
-            shard.flush()
-            shard_b.flush()
+    def drain():
+        # pingpong: the shards' threads have enqueued everything handed to them, then their streams have drained; every wait
+        # is the library's bounded one (rpf_shard_drain: RPF_WAIT_TIMEOUT_MS, 30 s) — a neighbour that never arrives ends
+        # in a GpuComputeError naming rank and phase, not in a run killed at the driver's limit with nothing written
+        if schedule == "pingpong":
+            shard.drain(pp_streams[0].cuda_stream)
+            shard_b.drain(pp_streams[1].cuda_stream)
+        elif sharded and shard is not None:
+            shard.drain(stream)
         torch.cuda.synchronize()
 
     preheat_steps = max(0, args.preheat)
@@ -401,10 +409,63 @@ def main():
     if schedule == "pingpong":   # the launches' own start / completion signals, summed inside the library (RPF_SHARD_TIMED)
         tn = [shard.timing(), shard_b.timing()]
         kern_avg_ms = (tn[0][1] + tn[1][1]) / max(1, tn[0][0] + tn[1][0])
-        kern_ms = [kern_avg_ms] * max(1, tn[0][0] + tn[1][0])
+        kern_ms = None   # the library sums the timed launches: a mean, no median / minimum
     else:
         kern_ms = sorted(e[0].elapsed_time(e[1]) for e in ev if e is not None)
         kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    # ---- N > 1: the same K steps again through the two-pipeline schedule (secondary.pingpong) ----------------------------
+    pp_result, stalled = None, False
+    if also_pingpong:
+        serial_schedule, schedule = schedule, "pingpong"
+        err = ""
+        try:
+            nstep[0] = 0
+            for _ in range(min(preheat_steps, 200) + args.warmup):
+                step()
+            drain()
+            shard.timing()
+            shard_b.timing()
+        except R.PhotoEditorError as ex:
+            err = str(ex)
+        def agree(e):   # every rank learns whether all of them got through
+            if world == 1:
+                return [e]
+            got = [None] * world
+            dist.all_gather_object(got, e)
+            return got
+        errs = agree(err)
+        if not any(errs):
+            try:
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    step(i)
+                drain()
+                dt2 = time.perf_counter() - t1
+                tn = [shard.timing(), shard_b.timing()]
+            except R.PhotoEditorError as ex:
+                err = str(ex)
+            errs = agree(err)
+        if any(errs):
+            stalled = True
+            pp_result = {"error": "; ".join(sorted({e for e in errs if e}))[:1500],
+                         "note": "the two-pipeline schedule did not complete on this node; the headline line above is the serial schedule"}
+        else:
+            if world > 1:
+                t = torch.tensor([dt2], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            job_mp = (rows if rehearse else (frame_h if mode == "strong" else world * rows)) * W / 1e6
+            pp_result = {"value": round(job_mp * args.steps / dt2, 1), "unit": "MP/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                         "kernel_ms_mean": round((tn[0][1] + tn[1][1]) / max(1, tn[0][0] + tn[1][0]), 4),
+                         "note": "schedule pingpong: TWO independent step pipelines per rank (two RCCL communicators with a thread each, "
+                                 "two streams, two band and output buffers, frames alternating); every step is still one exchange + "
+                                 "one launch.  Two frames are in flight, so this is throughput of a stream of frames, not the "
+                                 "latency of one; `value` of this line is the serial schedule"}
+        schedule = serial_schedule
+
     mp_per_step = (frame_h if mode == "strong" else world * rows) * W / 1e6   # the whole job: all ranks' pixels per step
     if rehearse:
         mp_per_step = rows * W / 1e6   # one band of the job is all that ran
@@ -474,8 +535,9 @@ def main():
                          }[schedule] if sharded else "")),
             "mode": mode, "schedule": (("none (halo once)" if halo_once else schedule) if sharded else None), "input_resident": "hbm" if batch else "infinity_cache",
             "variant": args.variant, "precision": args.precision, "out": args.out, "preheat_steps": preheat_steps,
-            "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 4), "kernel_ms_min": round(kern_ms[0], 4),
-            "kernel_timing": (f"HIP-event pairs around {len(kern_ms)} of the {args.steps} timed "
+            "kernel_ms_median": (round(kern_ms[len(kern_ms) // 2], 4) if kern_ms else None),
+            "kernel_ms_min": (round(kern_ms[0], 4) if kern_ms else None),
+            "kernel_timing": (f"HIP-event pairs around {len(kern_ms) if kern_ms else (tn[0][0] + tn[1][0])} of the {args.steps} timed "
                               + ("launches, by their own start / completion signals (hipExtLaunchKernelGGL events inside "
                                  "rpf_shard_develop_async; the exchange is a kernel of RCCL's in front of each)" if schedule == "pingpong" else
                                  "steps (the wait for the exchange sent one step earlier + the launch of one rpf_shard_develop call)"
@@ -638,8 +700,13 @@ def main():
             "legacy_512x512_mp_s_1t": round(legacy[1], 2), "legacy_512x512_mp_s_all_cores": round(legacy[cores], 2),
             "legacy_cores": cores, "single_thread_mp_s": round(args.cpu_rows * W / 1e6 / c1, 3),
         }
+    if pp_result is not None:
+        result.setdefault("secondary", {})["pingpong"] = pp_result
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if stalled:   # kernels of the stalled pipelines still sit on the device: leave without waiting for them
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         if shard is not None:
             torch.cuda.synchronize()

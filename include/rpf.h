@@ -363,15 +363,25 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
  * streams DIFFERENT priorities: with equal ones the pipelines can lock in phase (both exchanges at once, then both kernels
  * sharing the CUs: 37 us per step); a priority makes that state unstable and they settle in antiphase.
  * flags: RPF_SHARD_NO_EXCHANGE, RPF_SHARD_TIMED (the launch's own start / completion signals are a pair of timing events,
- * summed up by rpf_shard_timing).  Edit state set after the call may or may not reach a step that has not run yet; output
- * and band buffers must stay valid until the step's stream has passed it.
+ * summed up by rpf_shard_timing).  A step takes the edit state as it is at the call (by value).  Setters, rpf_add_mask and
+ * rpf_editor_destroy called while steps are still queued are safe: whatever would free or overwrite a device table first
+ * waits until the shard's thread has enqueued every step that references it, then for the device.  Output and band
+ * buffers are the caller's and must stay valid until the step's stream has passed it.
  * rpf_shard_flush: blocks until every step handed over has been ENQUEUED on its stream (then hipStreamSynchronize or an
- * event of the caller's is meaningful) and reports the first failure of such a step.
+ * event of the caller's is meaningful) and reports the first failure of such a step.  EVERY wait of this layer is bounded
+ * (rpf_shard_set_timeout, default RPF_WAIT_TIMEOUT_MS = 30 s; 0 = unbounded): on the deadline the call returns
+ * RPF_ERR_GPU_COMPUTE and rpf_last_error names the rank, its neighbours, the step that did not get enqueued and what the
+ * shard's thread was doing (the halo exchange: a neighbour never posted its half; the launch).
+ * rpf_shard_drain: flush, then wait — polling, with the same deadline — until `stream` has drained: the give-up-able
+ * replacement of hipStreamSynchronize behind a run of async steps (a step whose neighbour never arrives stalls on the
+ * DEVICE; after this error the process should report and exit, not retry).
  * rpf_shard_timing: flush, wait for the timed launches, return their number and summed duration since the last call
  * (at most 4096 launches are kept between two calls; further RPF_SHARD_TIMED steps run untimed). */
 int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
                             const rpf_raw_params* raw, void* d_out, int out_format, void* stream, uint32_t flags);
 int rpf_shard_flush(rpf_shard* s);
+int rpf_shard_drain(rpf_shard* s, void* stream);
+int rpf_shard_set_timeout(rpf_shard* s, int timeout_ms);
 int rpf_shard_timing(rpf_shard* s, uint32_t* launches, double* total_ms);
 
 /* Kernel variant selection for A/B measurements (bench.py --variant); 0 = shipped configuration.

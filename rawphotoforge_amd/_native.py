@@ -133,6 +133,8 @@ SYMBOLS = {
     "rpf_shard_develop_async": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp,
                                     C.c_uint32]),
     "rpf_shard_flush": (C.c_int, [_vp]),
+    "rpf_shard_drain": (C.c_int, [_vp, _vp]),
+    "rpf_shard_set_timeout": (C.c_int, [_vp, C.c_int]),
     "rpf_shard_timing": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_double)]),
 }
 

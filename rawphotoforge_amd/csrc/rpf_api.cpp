@@ -3,8 +3,10 @@
 // image.rs) re-stated over HIP.  No torch, no CPU compute path: every pixel is produced by
 // the gfx950 kernels in rpf_kernels.hip or not at all.
 #include <hip/hip_runtime_api.h>
+#include <stdlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <new>
 #include <string>
@@ -91,6 +93,37 @@ void api_processor_unref(rpf_processor* p) { processor_unref(p); }
 
 static size_t npix_of(const rpf_editor* e) { return (size_t)e->geom.rows * e->geom.width; }
 
+namespace rpf {
+int api_wait_timeout_ms()
+{
+    static const int ms = [] {
+        const char* v = getenv("RPF_WAIT_TIMEOUT_MS");
+        return v && *v ? atoi(v) : 30000;
+    }();
+    return ms;
+}
+
+int api_editor_quiesce(rpf_editor* e)
+{
+    {   // steps a shard's thread still holds (with copies of this editor's table pointers): enqueued first
+        std::unique_lock<std::mutex> lock(e->qmu);
+        const int ms = api_wait_timeout_ms();
+        auto idle = [&] { return e->queued == 0; };
+        if (ms > 0) {
+            if (!e->qcv.wait_for(lock, std::chrono::milliseconds(ms), idle))
+                return fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: " + std::to_string(e->queued) + " step(s) handed to rpf_shard_develop_async "
+                            "were not enqueued within " + std::to_string(ms) + " ms: the editor's tables are still referenced "
+                            "(rpf_shard_flush reports what the shard's thread is waiting for)");
+        } else {
+            e->qcv.wait(lock, idle);
+        }
+    }
+    if (e->foreign_streams) HIP_TRY(hipDeviceSynchronize());   // launches went to streams of the caller's
+    else if (e->stream) HIP_TRY(hipStreamSynchronize(e->stream));
+    return ok();
+}
+}  // namespace rpf
+
 // Refresh the device copy of params / curves / masks if a setter ran since the last upload.
 static int sync_edit_state_impl(rpf_editor* e);
 static int sync_edit_state(rpf_editor* e)
@@ -110,16 +143,20 @@ static int sync_edit_state_impl(rpf_editor* e)
     // place), read by the kernels instead of a square root, a quotient and a pow(t, 1.5) per pixel.
     if (e->state.masks[0].params.vignette != 0 && e->flavour == RPF_FLAVOUR_ACTIVE && !e->d_vign_falloff && npix_of(e) > 0 &&
         npix_of(e) * sizeof(float) <= 0xffffffffull) {
-        HIP_TRY(hipMalloc((void**)&e->d_vign_falloff, npix_of(e) * sizeof(float)));
-        HIP_TRY(launch_vignette_falloff(e->geom, e->d_vign_falloff, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));  // rpf_dev_* callers launch on their own streams
+        float* map = nullptr;  // the editor's pointer is set only once the map is complete: a failed build leaves no map behind
+        HIP_TRY(hipMalloc((void**)&map, npix_of(e) * sizeof(float)));
+        hipError_t he = launch_vignette_falloff(e->geom, map, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);  // rpf_dev_* callers launch on their own streams
+        if (he != hipSuccess) { (void)hipFree(map); return hip_fail(he, "vignette falloff map"); }
+        e->d_vign_falloff = map;
         e->dev.vign_falloff = e->d_vign_falloff;   // (vign_strength != 0 was or is being uploaded with this very state)
     }
     if (e->uploaded_params == e->state.params_version && e->uploaded_masks == e->state.masks_version) return ok();
     const bool masks_changed = e->uploaded_masks != e->state.masks_version;
     bool synced = false;  // kernels launched earlier (on this editor's stream or a caller's) may still read the old tables
     auto quiesce = [&]() -> int {
-        if (!synced) HIP_TRY(hipDeviceSynchronize());
+        if (!synced)
+            if (int qrc = api_editor_quiesce(e)) return qrc;
         synced = true;
         return ok();
     };
@@ -395,7 +432,12 @@ void rpf_editor_destroy(rpf_editor* e)
 {
     if (!e) return;
     if (e->proc && hipSetDevice(e->proc->device) == hipSuccess) {
+        // steps still queued in a shard's thread hold pointers into the tables freed below; should they not get enqueued
+        // within the deadline the tables are leaked rather than freed under a kernel that may still be launched
+        const bool idle = api_editor_quiesce(e) == RPF_OK;
         if (e->stream) (void)hipStreamSynchronize(e->stream);
+        if (!idle) { e->d_bright = nullptr; e->d_hsl = nullptr; e->d_masks = nullptr; e->d_mask_bits = nullptr;
+                     e->d_vign_falloff = nullptr; e->d_hue_fused_alloc = nullptr; }
         void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits,
                         e->d_vign_falloff, e->d_hue_fused_alloc};
         for (void* b : bufs)
@@ -902,6 +944,7 @@ int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* 
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only: use rpf_dev_demosaic, "
                                               "then rpf_dev_apply, for the Godot-legacy flavour");
+    if ((hipStream_t)stream != e->stream) e->foreign_streams = true;
     e->dev.flags = 0;
     HIP_TRY(launch_develop(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->dev, d_out, out_format,
                            (hipStream_t)stream));
@@ -934,6 +977,7 @@ int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_st
                     "lens distortion resamples the whole frame: unpack + demosaic first, then rpf_dev_apply on the full frame");
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
+    if ((hipStream_t)stream != e->stream) e->foreign_streams = true;
     e->dev.flags = 0;
     HIP_TRY(launch_develop_packed(cfg_of(e->proc), d_packed, (uint32_t)row_stride, bits, order, make_raw_params(*raw), e->geom,
                                   e->dev, d_out, out_format, (hipStream_t)stream));
@@ -949,6 +993,7 @@ int rpf_dev_apply(rpf_editor* e, const float* d_rgba_in, void* d_out, int out_fo
     if ((rc = sync_edit_state(e))) return rc;
     if (e->dev.lens_strength != 0.0f && (e->geom.y0 != 0 || e->geom.rows != e->geom.height))
         return fail(RPF_ERR_INVALID_ARGUMENT, "lens distortion resamples the whole frame: the tile must be the frame");
+    if ((hipStream_t)stream != e->stream) e->foreign_streams = true;
     e->dev.flags = flavour_flags(e);  // legacy: d_rgba_in is taken as sRGB-encoded, as that shader's input is
     HIP_TRY(launch_apply(cfg_of(e->proc), d_rgba_in, e->geom, e->dev, d_out, out_format, (hipStream_t)stream));
     return ok();

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -62,6 +64,15 @@ struct rpf_editor {
     std::vector<CurveStamps> uploaded_curves;  // per mask slot: EditParameters::curve_ver of what the device holds
     rpf::DeviceEdit dev{};
     hipStream_t stream = nullptr;
+    // Steps handed to a shard's thread (rpf_shard_develop_async) that the thread has not enqueued yet.  Each holds a COPY of
+    // `dev` — raw pointers to d_bright / d_hsl / d_mask_bits / the fused hue table / the falloff map — so nothing may free or
+    // overwrite those tables, and the editor may not go away, before the count is back at zero (api_editor_quiesce).
+    std::mutex qmu;
+    std::condition_variable qcv;
+    int queued = 0;
+    // a launch that reads this editor's tables went to a stream other than `stream` (rpf_dev_*, rpf_shard_*): quiescing
+    // then means the whole device; an editor driven through the operator layer alone waits for its own stream only
+    bool foreign_streams = false;
 
     rpf_editor(uint32_t w, uint32_t h) : state(w, h) {}
 };
@@ -73,6 +84,11 @@ int api_fail(int code, const std::string& msg);
 int api_hip_fail(hipError_t e, const char* what);
 // refresh the device copy of params / curves / masks if a setter ran since the last upload (rpf_api.cpp)
 int api_sync_edit_state(rpf_editor* e);
+// Nothing reads the editor's device tables any more: steps still queued in a shard's thread have been enqueued (bounded
+// wait, api_wait_timeout_ms; an error names what did not happen) and every launch that could read them has completed.
+int api_editor_quiesce(rpf_editor* e);
+// RPF_WAIT_TIMEOUT_MS (default 30000; 0 = no bound): the longest any call of this library waits for another thread or rank
+int api_wait_timeout_ms();
 // Arc<GpuProcessor>: drop one reference (the device tables go with the last one)
 void api_processor_unref(rpf_processor* p);
 inline LaunchCfg cfg_of(const rpf_processor* p) { return LaunchCfg{p->num_cus, p->variant}; }

@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -168,9 +170,15 @@ struct rpf_shard {
         uint32_t rows;
         bool exchange, timed;
         hipStream_t stream;
+        rpf_editor* ed;  // its `queued` count is dropped when the step has been enqueued (rpf_internal.h)
     };
     struct Work { Ahead* ahead; Step* step; };
     int in_flight = 0;           // steps handed over and not yet enqueued
+    // progress of the shard's thread, for the message of a wait that ran into its deadline (rpf_shard_flush)
+    uint64_t steps_handed = 0, steps_enqueued = 0;
+    std::atomic<const char*> phase{"idle"};
+    hipStream_t last_stream = nullptr;  // of the most recent step handed over (rpf_shard_drain)
+    int timeout_ms = -1;                // rpf_shard_set_timeout; -1: api_wait_timeout_ms()
     int async_rc = 0;            // the first failure of such a step, for rpf_shard_flush
     std::string async_error;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;  // start / stop of the timed launches since the last rpf_shard_timing
@@ -255,10 +263,18 @@ void exchange_worker(rpf_shard* s)
         }
         if (w.step) {  // a whole step: exchange + launch on its stream
             const int rc = run_step(s, *w.step);
+            s->phase.store("idle");
+            {   // the step's copy of the editor's table pointers is no longer needed: setters / destroy may proceed
+                rpf_editor* ed = w.step->ed;
+                std::lock_guard<std::mutex> qlock(ed->qmu);
+                --ed->queued;
+                ed->qcv.notify_all();
+            }
             delete w.step;
             std::lock_guard<std::mutex> lock(s->mu);
             if (rc && !s->async_rc) { s->async_rc = rc; s->async_error = rpf_last_error(); }
             --s->in_flight;
+            ++s->steps_enqueued;
         } else {
             rpf_shard::Ahead* a = w.ahead;
             int rc = RPF_OK;
@@ -280,7 +296,9 @@ void exchange_worker(rpf_shard* s)
 int run_step(rpf_shard* s, const rpf_shard::Step& t)
 {
     int rc = RPF_OK;
+    s->phase.store("halo exchange (ncclGroupStart ... ncclGroupEnd)");
     if (t.exchange && (rc = enqueue_exchange(s, const_cast<unsigned char*>(t.b.band), t.row_bytes, t.rows, t.stream))) return rc;
+    s->phase.store("launch");
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     bool timed = t.timed;
     if (timed) {
@@ -289,19 +307,29 @@ int run_step(rpf_shard* s, const rpf_shard::Step& t)
         else if (!s->timing_free.empty()) { ev = s->timing_free.back(); s->timing_free.pop_back(); }
     }
     if (timed && !ev.first) {
-        HIP_TRY(hipEventCreate(&ev.first));
-        HIP_TRY(hipEventCreate(&ev.second));
+        hipError_t he = hipEventCreate(&ev.first);
+        if (he == hipSuccess && (he = hipEventCreate(&ev.second)) != hipSuccess) { (void)hipEventDestroy(ev.first); ev.first = nullptr; }
+        if (he != hipSuccess) return api_hip_fail(he, "hipEventCreate(timed launch)");
     }
     // A step that exchanges is one of two pipelines: its launch leaves a CU per XCD to the OTHER pipeline's exchange, which
     // starts while this kernel runs — RCCL's workgroup needs a CU of its own (the fused kernel's persistent workgroups
     // fill theirs), and a persistent workgroup that has to wait for that CU makes its whole launch late.
     static const int reserve = getenv("RPF_SHARD_ASYNC_RESERVE") ? atoi(getenv("RPF_SHARD_ASYNC_RESERVE")) : 8;
-    HIP_TRY(launch_part(t.b, PART_ALL, t.stream, ev.second, ev.first, t.exchange ? reserve : 0));
-    if (timed) {
+    const hipError_t le = launch_part(t.b, PART_ALL, t.stream, ev.second, ev.first, t.exchange ? reserve : 0);
+    if (timed) {  // the pair goes back to the pool whether or not the launch took it
         std::lock_guard<std::mutex> lock(s->mu);
-        s->timing.push_back(ev);
+        (le == hipSuccess ? s->timing : s->timing_free).push_back(ev);
     }
+    if (le != hipSuccess) return api_hip_fail(le, "fused launch of an async step");
     return RPF_OK;
+}
+
+int shard_deadline_ms(const rpf_shard* s) { return s->timeout_ms >= 0 ? s->timeout_ms : api_wait_timeout_ms(); }
+
+std::string shard_who(const rpf_shard* s)
+{
+    return "rank " + std::to_string(s->rank) + " of " + std::to_string(s->world) + " (neighbour above " + std::to_string(s->up) +
+           ", below " + std::to_string(s->down) + ", shard " + std::to_string((unsigned long long)(uintptr_t)s % 100000) + ")";
 }
 
 }  // namespace
@@ -492,6 +520,7 @@ int prepare_band_launch(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_st
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return api_fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
     e->dev.flags = 0;
+    e->foreign_streams = true;  // the launch goes to a stream of the caller's (api_editor_quiesce)
     b = BandLaunch{e->proc, e->geom, e->dev, static_cast<const unsigned char*>(d_band), (uint32_t)row_stride, bits, order,
                    make_raw_params(*raw), d_out, out_format};
     return RPF_OK;
@@ -561,16 +590,29 @@ int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t ro
             return api_fail(RPF_ERR_INVALID_ARGUMENT, "this band has an exchange ahead: its step is rpf_shard_develop's");
     const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
     rpf_shard::Step* t = new (std::nothrow) rpf_shard::Step{b, row_bytes, b.geom.rows, exchange, (flags & RPF_SHARD_TIMED) != 0,
-                                                           (hipStream_t)stream};
+                                                           (hipStream_t)stream, e};
     if (!t) return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: out of host memory");
+    {   // from here until the shard's thread has enqueued the step, the editor's tables are pinned (api_editor_quiesce)
+        std::lock_guard<std::mutex> qlock(e->qmu);
+        ++e->queued;
+    }
     try {
         std::lock_guard<std::mutex> lock(s->mu);
         s->work.push_back(rpf_shard::Work{nullptr, t});
         ++s->in_flight;
+        ++s->steps_handed;
+        s->last_stream = (hipStream_t)stream;
         if (!s->worker.joinable()) s->worker = std::thread(exchange_worker, s);
     } catch (...) {
-        std::lock_guard<std::mutex> lock(s->mu);
-        if (!s->work.empty() && s->work.back().step == t) { s->work.pop_back(); --s->in_flight; }
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            if (!s->work.empty() && s->work.back().step == t) { s->work.pop_back(); --s->in_flight; --s->steps_handed; }
+        }
+        {
+            std::lock_guard<std::mutex> qlock(e->qmu);
+            --e->queued;
+            e->qcv.notify_all();
+        }
         delete t;
         return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: could not start the shard's thread");
     }
@@ -579,20 +621,68 @@ int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t ro
     return RPF_OK;
 }
 
+int rpf_shard_set_timeout(rpf_shard* s, int timeout_ms)
+{
+    if (!s) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null shard");
+    s->timeout_ms = timeout_ms;
+    return RPF_OK;
+}
+
 int rpf_shard_flush(rpf_shard* s)
 {
     if (!s) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null shard");
     std::unique_lock<std::mutex> lock(s->mu);
-    s->cv.wait(lock, [&] { return s->in_flight == 0; });
+    const int ms = shard_deadline_ms(s);
+    auto idle = [&] { return s->in_flight == 0; };
+    if (ms > 0) {
+        if (!s->cv.wait_for(lock, std::chrono::milliseconds(ms), idle)) {
+            // the thread is stuck in a call that does not return — a neighbour that never posted its half of the exchange,
+            // a launch behind a full queue: say where, and leave the steps where they are (they may still complete)
+            const std::string msg = "GPU compute error: " + shard_who(s) + ": step " + std::to_string(s->steps_enqueued + 1) + " of the " +
+                                    std::to_string(s->steps_handed) + " handed to rpf_shard_develop_async was not enqueued within " +
+                                    std::to_string(ms) + " ms; the shard's thread is in: " + s->phase.load();
+            lock.unlock();
+            return api_fail(RPF_ERR_GPU_COMPUTE, msg);
+        }
+    } else {
+        s->cv.wait(lock, idle);
+    }
     if (s->async_rc) {
         const int rc = s->async_rc;
-        const std::string msg = s->async_error;
+        const std::string msg = shard_who(s) + ": " + s->async_error;
         s->async_rc = 0;
         s->async_error.clear();
         lock.unlock();
         return api_fail(rc, msg);
     }
     return RPF_OK;
+}
+
+int rpf_shard_drain(rpf_shard* s, void* stream)
+{
+    if (!s) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null shard");
+    int rc = rpf_shard_flush(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->proc->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int ms = shard_deadline_ms(s);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
+    for (;;) {  // polled: a wait that can be given up (hipStreamSynchronize cannot)
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return RPF_OK;
+        if (q != hipErrorNotReady) return api_hip_fail(q, "hipStreamQuery(step stream)");
+        if (ms > 0 && std::chrono::steady_clock::now() > t_end) {
+            uint64_t enq, handed;
+            {
+                std::lock_guard<std::mutex> lock(s->mu);
+                enq = s->steps_enqueued; handed = s->steps_handed;
+            }
+            return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: " + shard_who(s) + ": all " + std::to_string(enq) + " of " +
+                            std::to_string(handed) + " steps are enqueued but their stream has not drained within " + std::to_string(ms) +
+                            " ms: a halo exchange is waiting on the device for a neighbour that has not reached the same step");
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
 int rpf_shard_timing(rpf_shard* s, uint32_t* launches, double* total_ms)

@@ -483,8 +483,17 @@ class Shard:
                                                C.c_void_p(d_out_ptr), out_format, C.c_void_p(stream), flags))
 
     def flush(self) -> None:
-        """Block until every step handed to develop_async is enqueued on its stream; raises its first failure."""
+        """Block (bounded: set_timeout) until every step handed to develop_async is enqueued on its stream; raises its first
+        failure, or GpuComputeError naming rank, neighbours and the stuck step when the deadline passes."""
         _check(N.lib().rpf_shard_flush(self._h))
+
+    def drain(self, stream: int = 0) -> None:
+        """flush(), then a bounded, polling wait for `stream` to drain (rpf_shard_drain)."""
+        _check(N.lib().rpf_shard_drain(self._h, C.c_void_p(stream)))
+
+    def set_timeout(self, timeout_ms: int) -> None:
+        """The deadline of every wait of this shard in ms (0 = unbounded; default RPF_WAIT_TIMEOUT_MS or 30 s)."""
+        _check(N.lib().rpf_shard_set_timeout(self._h, int(timeout_ms)))
 
     def timing(self):
         """(number, summed milliseconds) of the SHARD_TIMED launches since the last call (waits for them)."""

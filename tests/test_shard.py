@@ -407,7 +407,7 @@ def test_bench_two_ranks_rehearsal_and_rccl_fallback(tmp_path):
 
 
 @gpu_only
-@pytest.mark.parametrize("schedule", ["pingpong", "ahead", "serial", "once"])
+@pytest.mark.parametrize("schedule", ["auto", "pingpong", "ahead", "serial", "once"])
 def test_bench_sharded_code_path_rehearsed_on_one_gpu(schedule):
     """The N > 1 branch of bench.py with the LIBRARY's communicator (what the driver's --gpus N run takes on a node),
     rehearsed in one process: rank 4 of 8's band of THE frame, the rank its own neighbour.  The default there is two
@@ -420,17 +420,22 @@ def test_bench_sharded_code_path_rehearsed_on_one_gpu(schedule):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--preheat", "5",
            "--rehearse-ranks", "8"] + {"serial": ["--schedule", "serial"], "once": ["--halo", "once"],
-                                       "ahead": ["--schedule", "ahead"], "pingpong": []}[schedule]
+                                       "ahead": ["--schedule", "ahead"], "pingpong": ["--schedule", "pingpong"], "auto": []}[schedule]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
     c = r["config"]
-    assert c["schedule"] == ("none (halo once)" if schedule == "once" else schedule)
+    # the default: the headline line is exchange-then-launch on one stream, the two-pipeline schedule runs after it and is
+    # reported under secondary.pingpong
+    assert c["schedule"] == {"once": "none (halo once)", "auto": "serial"}.get(schedule, schedule)
+    if schedule == "auto":
+        pp = r["secondary"]["pingpong"]
+        assert "error" not in pp and pp["value"] > 0 and pp["ms_per_step"] > 0
     assert ("EDITING SESSION" in c["workload"]) == (schedule == "once")
     assert c["mode"] == "strong" and "REHEARSAL of rank 4 of 8" in c["workload"]
     assert c["ranks"][0]["band"] == [2000, 500] and c["ranks"][0]["neighbours"] == [0, 0]
     assert "one-rank" in c["exchange"] and r["n_gpus"] == 1
     assert r["value"] > 0 and abs(r["ms_per_step"] - 3.0 / r["value"] * 1e3) < 1e-2 * r["ms_per_step"]
-    assert "secondary" not in r and "cpu_baseline" not in r
+    assert (schedule == "auto" or "secondary" not in r) and "cpu_baseline" not in r

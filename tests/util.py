@@ -43,6 +43,18 @@ def build_checker(force=False) -> str:
     return CHECKER_LIB
 
 
+# The test-only RCCL stand-in (tests/rccl_standin): several processes on one GPU as the ranks of the library's communicators.
+STANDIN_SRC = os.path.join(ROOT, "tests", "rccl_standin", "rccl_standin.cpp")
+STANDIN_LIB = os.path.join(ROOT, "tests", "rccl_standin", "librccl_standin.so")
+
+
+def build_standin(force=False) -> str:
+    if force or not os.path.exists(STANDIN_LIB) or os.path.getmtime(STANDIN_LIB) < os.path.getmtime(STANDIN_SRC):
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-fPIC", "-shared", STANDIN_SRC,
+                        "-o", STANDIN_LIB, "-lrt"], check=True)
+    return STANDIN_LIB
+
+
 _twin = None
 
 
