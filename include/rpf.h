@@ -202,13 +202,15 @@ int rpf_set_shader_flavour(rpf_editor* e, int flavour);
  *   source order — bit-identical to the parity oracle on every input (what all parity claims of this library refer to).
  * RPF_PRECISION_FAST: binary32 only.  pow, sqrt, cos, sin within 1 ulp of the correctly rounded value; the hue index from a
  *   binary32 polynomial (differs from the exact index, by one, within 0.005 index units of a boundary: about 0.1 % of
- *   directions); a * b + c contracted to an fma in the 3x3 colour matrices and the gamma's affine step.  Everything up to and
- *   including the brightness curve stays bit-identical to EXACT.  Measured against the oracle on uniformly random frames:
- *   median 1 ulp per channel, 99.6 % of the pixels within 1e-5, the rest (hue-index flips: the hue moves by one step of the
- *   index scale, so a steep per-hue curve scales the difference) within 2e-3 for the default curves (tests/test_fast_math.py,
- *   tests/test_gpu_fast.py).  A hint: launches that have no binary32 specialisation (user masks, packed input, the
- *   RGBA pass) compute the exact chain.  Not versioned edit state: takes effect at the next apply / rpf_dev_* call.
- *   No reference counterpart (wgpu has one precision, the driver's). */
+ *   directions); a * b + c contracted to an fma in the 3x3 colour matrices and the gamma's affine step; and where no mask has
+ *   a hue curve (the reference default) the chroma / hue round trip — length, atan2, index, cos, sin — is replaced by the
+ *   rotation of (a, b) through the index-quantisation residue that it amounts to (rpf_chain.h edit_chain_fast).  Everything
+ *   up to and including the brightness curve stays bit-identical to EXACT.  Measured against the oracle on uniformly random
+ *   frames: median 1-2 ulp per channel, 92-98 % of the pixels within 1e-6 and 99.6 % within 1e-5; the rest sit where the hue
+ *   index steps (the hue moves by one step of the index scale there, in the reference too: within 2e-3 for the default
+ *   curves; a steep per-hue curve scales that) (tests/test_fast_math.py, tests/test_gpu_fast.py).  A hint: launches that
+ *   have no binary32 specialisation (user masks, packed input, the RGBA pass) compute the exact chain.  Not versioned edit
+ *   state: takes effect at the next apply / rpf_dev_* call.  No reference counterpart (wgpu has one precision, the driver's). */
 enum { RPF_PRECISION_EXACT = 0, RPF_PRECISION_FAST = 1 };
 int rpf_set_precision(rpf_editor* e, int precision);
 int rpf_get_precision(const rpf_editor* e, int* precision);

@@ -477,7 +477,16 @@ RPF_HD float dot3_fast(float c0, float c1, float c2, float x, float y, float z)
     return __builtin_fmaf(c2, z, __builtin_fmaf(c1, y, c0 * x));
 }
 
-template <int N, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
+// HUE_ROT (the caller's promise: every mask's hue curve is the identity — the reference default, every edit set without a
+// hue curve): the chain then needs neither the chroma nor an angle.  Replacing the hue h by f32(u32(h 65535)) / 65535 turns
+// (a, b) through the residue eps = (h 65535 - u32(h 65535)) 2 pi / 65535 < 9.6e-5, so what wgsl:77-84 computes as
+// C cos(2 pi h'), C sin(2 pi h') with C = length(a, b) is (a + b eps, b - a eps) up to eps^2 / 2 < 5e-9 relative — no sqrt,
+// no atan2, no cos, no sin, and nothing that can flip: eps is continuous in (a, b) except where the index steps, where
+// the reference's own result steps by the same amount.  Against the builtin route: eps is known to 5e-8 rad (rpf_fast.h
+// hue_fraction_fast) and the reference rounds its angle to binary32 (2.4e-7 rad at 2 pi), so the two differ by up to
+// C 3e-7, the size of the other roundings of this mode.  Saturation gains scale (a, b), lightness gains L, as before; a
+// mask with saturation / lightness CURVES still needs the index for its look-up (the full position, wave-uniform branch).
+template <int N, int STATIC_FLAGS = -1, bool HUE_ROT = false, class Params, class Luts, class Tabs>
 RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N], const Params& mp,
                             uint32_t num_masks, const Luts& luts, const Tabs& T)
 {
@@ -501,6 +510,7 @@ RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const u
 
     // linear_srgb_to_oklch, wgsl:64-75
     float L[N], C[N], hk[N];  // hk: the hue as the integer k of h = k / 65535, held as binary32
+    float A[N], Bq[N];        // HUE_ROT: (a, b) themselves; C is then the product of the saturation gains
     for (int n = 0; n < N; ++n) {
         const float l = dot3_fast(RPF_F(0.4122214708), RPF_F(0.5363325363), RPF_F(0.0514459929), r[n], g[n], b[n]);
         const float mm = dot3_fast(RPF_F(0.2119034982), RPF_F(0.6806995451), RPF_F(0.1073969566), r[n], g[n], b[n]);
@@ -509,18 +519,28 @@ RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const u
         const float mc = powc_fast<POW_CBRT>(mm, T.cbrt);
         const float sc = powc_fast<POW_CBRT>(s, T.cbrt);
         L[n] = dot3_fast(RPF_F(0.2104542553), RPF_F(0.7936177850), RPF_F(-0.0040720468), lc, mc, sc);
-        const float A = dot3_fast(RPF_F(1.9779984951), RPF_F(-2.4285922050), RPF_F(0.4505937099), lc, mc, sc);
-        const float Bq = dot3_fast(RPF_F(0.0259040371), RPF_F(0.7827717662), RPF_F(-0.8086757660), lc, mc, sc);
-        C[n] = sqrt_fast(__builtin_fmaf(Bq, Bq, A * A));
-        hk[n] = __builtin_truncf(hue_position_fast(Bq, A));  // f32(u32(h * 65535)), wgsl:320
+        A[n] = dot3_fast(RPF_F(1.9779984951), RPF_F(-2.4285922050), RPF_F(0.4505937099), lc, mc, sc);
+        Bq[n] = dot3_fast(RPF_F(0.0259040371), RPF_F(0.7827717662), RPF_F(-0.8086757660), lc, mc, sc);
+        if constexpr (HUE_ROT) {
+            C[n] = 1.0f;
+            hk[n] = -1.0f;  // the index: only if a mask's saturation / lightness curve asks for it (below)
+        } else {
+            C[n] = sqrt_fast(__builtin_fmaf(Bq[n], Bq[n], A[n] * A[n]));
+            hk[n] = __builtin_truncf(hue_position_fast(Bq[n], A[n]));  // f32(u32(h * 65535)), wgsl:320
+        }
     }
 
     // per-mask OKLCH curves, wgsl:312-331
+    bool have_index = !HUE_ROT;
     auto oklch_stage = [&](uint32_t m, bool main_mask) {
         const MaskParams P = main_mask ? mask_params_main(mp) : mask_params_user(mp, m);
         const uint32_t pflags = (main_mask && STATIC_FLAGS >= 0) ? (uint32_t)STATIC_FLAGS : P.flags;
         const bool trivial = (pflags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
                              (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
+        if (HUE_ROT && !trivial && !have_index) {  // wave-uniform: the first mask with a saturation / lightness curve
+            for (int n = 0; n < N; ++n) hk[n] = __builtin_truncf(hue_position_fast(Bq[n], A[n]));
+            have_index = true;
+        }
         for (int n = 0; n < N; ++n) {
             // a user mask re-derives the index from the hue the previous mask left, u32(f32(k / 65535) * 65535) — which is
             // k again for every k (tests/test_fast_math.py), so the integer is carried instead
@@ -531,10 +551,10 @@ RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const u
             if (!trivial) {
                 uint32_t nh;
                 luts.hsl(m, (uint32_t)hu_f, P, nh, sat_gain, light_gain);
-                nh_f = (float)nh;
+                nh_f = (float)nh;  // (HUE_ROT: the identity)
             }
             const bool on = main_mask ? true : (bool)((active[n] >> m) & 1u);
-            hk[n] = on ? nh_f : hk[n];
+            if (!HUE_ROT) hk[n] = on ? nh_f : hk[n];
             C[n] = on ? C[n] * sat_gain : C[n];
             L[n] = on ? L[n] * light_gain : L[n];
         }
@@ -545,9 +565,16 @@ RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const u
 
     // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336)
     for (int n = 0; n < N; ++n) {
-        float cs, sn;
-        sincos_hue_fast(hk[n], cs, sn);
-        const float oa = C[n] * cs, ob = C[n] * sn;
+        float oa, ob;
+        if constexpr (HUE_ROT) {
+            const float eps = hue_fraction_fast(Bq[n], A[n]) * RPF_K_HUE_STEP_F;
+            oa = __builtin_fmaf(Bq[n], eps, A[n]) * C[n];
+            ob = __builtin_fmaf(-A[n], eps, Bq[n]) * C[n];
+        } else {
+            float cs, sn;
+            sincos_hue_fast(hk[n], cs, sn);
+            oa = C[n] * cs; ob = C[n] * sn;
+        }
         const float l_ = __builtin_fmaf(RPF_F(0.2158037573), ob, __builtin_fmaf(RPF_F(0.3963377774), oa, L[n]));
         const float m_ = __builtin_fmaf(RPF_F(-0.0638541728), ob, __builtin_fmaf(RPF_F(-0.1055613458), oa, L[n]));
         const float s_ = __builtin_fmaf(RPF_F(-1.2914855480), ob, __builtin_fmaf(RPF_F(-0.0894841775), oa, L[n]));

@@ -183,6 +183,51 @@ RPF_HD float hue_position_fast(float y, float x)
     return v;
 }
 
+// The same position's FRACTIONAL part alone, i.e. how far the direction (x, y) lies past the boundary of its hue index, in
+// index units in [0, 1): all a launch needs when every hue curve is the identity (edit_chain_fast's HUE_ROT).  The first
+// octant's position p q is below 8192 (ulp 2^-11); its fraction is exact, and each reflection c - position acts on
+// fractions: frac(c - v) = fract(frac(c) - frac(v)) with frac(c) in {0.75, 0.5, 0}.  Accurate to 0.0005 index units
+// (5e-8 rad) all round the circle — the full position above loses that to the binary32 grid near 65535 (0.004).
+RPF_HD float hue_fraction_fast(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float mx, mn;
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
+    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
+    const float q = mn * __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(mx, 0x1p-100f, 0x1p+100f));
+#else
+    const float mx = ax > ay ? ax : ay;
+    const float mn = ax > ay ? ay : ax;
+    const float mxc = mx < 0x1p-100f ? 0x1p-100f : (mx > 0x1p+100f ? 0x1p+100f : mx);
+    const float q = mn / mxc;
+#endif
+    const float z = q * q;
+    float p = __builtin_fmaf(z, -42.290016174316406f, 228.035400390625f);
+    p = __builtin_fmaf(z, p, -583.177734375f);
+    p = __builtin_fmaf(z, p, 1005.7022705078125f);
+    p = __builtin_fmaf(z, p, -1450.700439453125f);
+    p = __builtin_fmaf(z, p, 2080.470458984375f);
+    p = __builtin_fmaf(z, p, -3476.37744140625f);
+    p = __builtin_fmaf(z, p, 10430.2119140625f);
+    const float v = p * q;  // [0, 8191.875]
+    auto fract = [](float t) {  // t - floor(t), in [0, 1)
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_fractf(t);
+#else
+        return t - __builtin_floorf(t);
+#endif
+    };
+    float f = fract(v);
+    f = ay > ax ? fract(0.75f - f) : f;  // 16383.75 - v
+    f = x < 0.0f ? fract(0.5f - f) : f;  // 32767.5 - v
+    f = y < 0.0f ? fract(-f) : f;        // 65535 - v
+    return f;
+}
+
+// 2 * f32(pi) / 65535 as binary32: one index step in radians
+#define RPF_K_HUE_STEP_F ((float)RPF_K_HUE_STEP)
+
 RPF_HD float sqrt_fast(float s)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -205,6 +205,27 @@ extern "C" int gpu_fast_hue_position(const float* y, const float* x, uint64_t n,
     return rc;
 }
 
+__global__ void k_fast_hue_fraction(const float* y, const float* x, uint64_t n, float* out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = rpf::hue_fraction_fast(y[i], x[i]);
+}
+
+extern "C" int gpu_fast_hue_fraction(const float* y, const float* x, uint64_t n, float* out)
+{
+    float *dy = nullptr, *dx = nullptr, *dout = nullptr;
+    if (hipMalloc((void**)&dy, n * 4) != hipSuccess || hipMalloc((void**)&dx, n * 4) != hipSuccess ||
+        hipMalloc((void**)&dout, n * 4) != hipSuccess)
+        return 1;
+    (void)hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_fast_hue_fraction, dim3(2048), dim3(256), 0, 0, dy, dx, n, dout);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    (void)hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout);
+    return rc;
+}
+
 // powc_fast (which: 0 = cube root, 1 = gamma) over the bit patterns [lo, lo + n) with the table the host built, and
 // sincos_hue_fast for all 65536 indices: IEEE operations only, so these must be the host twin's bits
 __global__ void k_fast_pow_range(int which, uint32_t lo, uint64_t n, const rpf::FastTables* T, float* out)

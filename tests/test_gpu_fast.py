@@ -26,6 +26,8 @@ def checker(gpu):   # after the product library has initialised the device (its 
     lib.gpu_fast_sqrt_sweep.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32)]
     lib.gpu_fast_hue_position.restype = C.c_int
     lib.gpu_fast_hue_position.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.gpu_fast_hue_fraction.restype = C.c_int
+    lib.gpu_fast_hue_fraction.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.gpu_fast_pow_range.restype = C.c_int
     lib.gpu_fast_pow_range.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.gpu_fast_sincos_all.restype = C.c_int
@@ -87,6 +89,22 @@ def test_fast_hue_index_on_the_device(checker):
     assert (d != 0).mean() < 0.002, (d != 0).mean()
 
 
+def test_fast_hue_fraction_on_the_device(checker):
+    """hue_fraction_fast with the hardware reciprocal and v_fract_f32: within 0.003 index units of the binary64 value."""
+    rng = np.random.default_rng(7)
+    n = 4_000_000
+    th, rad = rng.uniform(0, 2 * np.pi, n), 10.0 ** rng.uniform(-4, 0, n)
+    x, y = (rad * np.cos(th)).astype(np.float32), (rad * np.sin(th)).astype(np.float32)
+    f = np.empty(n, np.float32)
+    assert checker.gpu_fast_hue_fraction(_P(y), _P(x), n, _P(f)) == 0
+    assert f.min() >= 0.0 and f.max() < 1.0
+    pos = np.arctan2(y.astype(np.float64), x.astype(np.float64)) / np.float64(np.float32(2.0 * 3.14159265359))
+    pos = np.where(pos < 0, pos + 1, pos) * 65535.0
+    d = np.abs(f - (pos - np.floor(pos)))
+    d = np.minimum(d, 1.0 - d)
+    assert d.max() < 0.003 and d.mean() < 0.001, (float(d.max()), float(d.mean()))
+
+
 # ---- the kernel --------------------------------------------------------------------------------------------------
 def _stats(got, want):
     got = np.asarray(got, np.float32).reshape(want.shape)[..., :3]
@@ -97,11 +115,13 @@ def _stats(got, want):
 
 
 def _assert_fast_bounds(got, want, what, flip_bound=4e-3):
-    """Median 1 ulp per channel; at least 99 % of the pixels within 1e-5; the others are hue-index flips: the hue moves by
-    one step of the index scale, which with smooth or trivial OKLCH curves stays below `flip_bound` (the gamma's slope at
-    dark values times 1 / 65535 of a turn of a saturated colour) — a steep hue / saturation / lightness curve scales it."""
+    """Median at most 2 ulp per channel; at least 85 % of the pixels within 1e-6 and 99 % within 1e-5; the others sit where
+    the hue index steps: the hue moves by one step of the index scale, which with smooth or trivial OKLCH curves stays below
+    `flip_bound` (the gamma's slope at dark values times 1 / 65535 of a turn of a saturated colour) — a steep hue /
+    saturation / lightness curve scales it."""
     ulp, ad = _stats(got, want)
-    assert np.median(ulp) <= 1, (what, float(np.median(ulp)))
+    assert np.median(ulp) <= 2, (what, float(np.median(ulp)))
+    assert (ad <= 1e-6).mean() >= 0.85, (what, float((ad <= 1e-6).mean()))
     assert (ad <= 1e-5).mean() >= 0.99, (what, float((ad <= 1e-5).mean()))
     assert ad.max() <= flip_bound, (what, float(ad.max()))
     assert np.array_equal(np.asarray(got, np.float32).reshape(want.shape)[..., 3], want[..., 3])  # alpha = 1
@@ -200,5 +220,5 @@ def test_fast_develop_full_frame_statistics(gpu):
     assert same > 0.01      # some pixels are bit-identical in all three channels (measured: 3.7 %)
     ei, fi = exact[..., :3].contiguous().view(torch.int32), fast[..., :3].contiguous().view(torch.int32)
     ulp = (ei - fi).abs()
-    assert float(ulp.float().median()) <= 1
+    assert float(ulp.float().median()) <= 2
     assert torch.equal(fast[..., 3], exact[..., 3])

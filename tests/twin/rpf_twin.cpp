@@ -176,6 +176,11 @@ void twin_fast_sincos_all(float* cs, float* sn)  // 65536 each
 {
     for (uint32_t k = 0; k < 65536; ++k) rpf::sincos_hue_fast((float)k, cs[k], sn[k]);
 }
+void twin_fast_hue_fraction_many(const float* y, const float* x, size_t n, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) out[i] = rpf::hue_fraction_fast(y[i], x[i]);
+}
 void twin_fast_hue_position_many(const float* y, const float* x, size_t n, float* out)
 {
 #pragma omp parallel for schedule(static)
@@ -229,16 +234,21 @@ struct HostFastTabs {
 };
 void twin_edit_chain_fast(const float* rgb, size_t npix, const rpf::MaskParams* mp, uint32_t num_masks,
                           const int32_t* bright, const int32_t* hue, const int32_t* sat, const int32_t* light,
-                          float* rgba_out)
+                          float* rgba_out, bool allow_rot = true)
 {
     HostLuts L{bright, hue, sat, light};
     const HostFastTabs T{fast_tabs().cbrt, fast_tabs().gamma};
     const uint32_t active = num_masks >= 32 ? 0xffffffffu : ((1u << num_masks) - 1u);
+    bool all_hue_identity = true;
+    for (uint32_t m = 0; m < num_masks; ++m) all_hue_identity = all_hue_identity && (mp[m].flags & rpf::MF_HUE_IDENTITY);
+    all_hue_identity = all_hue_identity && allow_rot;
 #pragma omp parallel for
     for (long long i = 0; i < (long long)npix; ++i) {
         float r[1] = {rgb[i * 3]}, g[1] = {rgb[i * 3 + 1]}, b[1] = {rgb[i * 3 + 2]};
         const uint32_t act[1] = {active};
-        rpf::edit_chain_fast<1>(r, g, b, act, mp, num_masks, L, T);
+        // as the kernels choose: without a hue curve on any mask, the rotation form (edit_chain_fast's HUE_ROT)
+        if (all_hue_identity) rpf::edit_chain_fast<1, -1, true>(r, g, b, act, mp, num_masks, L, T);
+        else rpf::edit_chain_fast<1>(r, g, b, act, mp, num_masks, L, T);
         rgba_out[i * 4] = r[0]; rgba_out[i * 4 + 1] = g[0]; rgba_out[i * 4 + 2] = b[0]; rgba_out[i * 4 + 3] = 1.0f;
     }
 }
@@ -274,7 +284,8 @@ void twin_apply_mode(const float* rgb, size_t npix, const twin_edit_params* ep, 
             p.curve[c].assign(src[c] + (size_t)m * RPF_CURVE_RESOLUTION, src[c] + (size_t)(m + 1) * RPF_CURVE_RESOLUTION);
         mp[m] = rpf::make_mask_params(p);
     }
-    if (fused == 2) twin_edit_chain_fast(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
+    if (fused == 2 || fused == 3)  // 3: the builtin route also where no mask has a hue curve (A/B of edit_chain_fast's HUE_ROT)
+        twin_edit_chain_fast(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out, fused == 2);
     else if (fused) twin_edit_chain_fused(rgb, npix, mp.data(), bright, hue, sat, light, rgba_out);
     else twin_edit_chain(rgb, npix, mp.data(), num_masks, bright, hue, sat, light, rgba_out);
 }

@@ -92,7 +92,7 @@ def twin_apply(rgb, masks_params, fused=False, fast=False) -> np.ndarray:
     out = np.empty((a.shape[0], 4), np.float32)
     twin().twin_apply_mode(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.shape[0]), ep, C.c_uint32(n),
                            *[l.ctypes.data_as(C.c_void_p) for l in luts], out.ctypes.data_as(C.c_void_p),
-                           C.c_int(2 if fast else (1 if fused else 0)))
+                           C.c_int((3 if fast == "builtins" else 2) if fast else (1 if fused else 0)))
     return out
 
 
