@@ -724,9 +724,6 @@ void k_stream(const StreamArgs a)
 // The price: two columns' rolling windows in registers (about 110 VGPRs, four waves per SIMD instead of five).
 // ---------------------------------------------------------------------------
 constexpr int HP_STRIP_W = 128;
-#ifndef RPF_HP_EVEN_VMCNT
-#define RPF_HP_EVEN_VMCNT 1
-#endif
 
 struct HpRow { float va, vb, p1a, p1b, p2a, p2b; };
 
@@ -922,20 +919,6 @@ void k_hp(const StreamArgs a)
         Raw4 n4 = load_row(4), n5 = load_row(5);
 
         Fall nf0 = load_fall(2 * pair0 - bp), nf1 = load_fall(2 * pair0 - bp + 1);
-        // Four stores that go nowhere (an empty descriptor: the hardware drops them), behind the first step's row loads.  A
-        // step's row loads are issued one step ahead and followed by that step's four stores; the counter the loads are
-        // waited for with (vmcnt) counts stores too, in order, so "these loads have arrived" is `vmcnt <= 4 + newer loads`
-        // inside the loop — but on the way INTO the loop nothing follows the loads, and the compiler, which must emit one
-        // wait for both ways of reaching the loop's top, emits the stricter one: vmcnt(0) in every step, i.e. a wait for
-        // the previous step's stores to be acknowledged by the L2 (15 % of the binary32 kernel: tmp_libs timing-only builds,
-        // profiles/r04_experiments.md).  With the same four stores behind the first loads both ways look alike.
-        if (RPF_HP_EVEN_VMCNT) {
-            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-            const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, RPF_BUFFER_RSRC_FLAGS);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)  // (four different offsets: identical stores would be merged into one)
-                __builtin_amdgcn_raw_buffer_store_b128(v4u{0u, 0u, 0u, 0u}, nowhere, 16u * (uint32_t)k, 0, 2);
-        }
         for (int p = 0; p < npairs; ++p) {  // wave-uniform
             const HpRow t4 = taps(n4, 0), t5 = taps(n5, 1);
             const int row = 2 * (pair0 + p) - bp;
