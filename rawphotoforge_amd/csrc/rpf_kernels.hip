@@ -163,18 +163,19 @@ enum { OUT_RGBA_F32_PLAIN = 3 };  // internal (A/B only): RGBA32F with ordinary 
 // ---------------------------------------------------------------------------
 template <bool LDS_LUT>
 struct DevLuts {
-    const uint16_t* lds_bright;  // mask 0's brightness curve in LDS (LDS_LUT)
+    const uint16_t* lds_bright;  // one mask's brightness curve in LDS (LDS_LUT): mask `lds_m`'s
     const uint16_t* g_bright;
     const ushort4* g_hsl;
     const HueBound* g_hue_bounds;
     const HueBoundCs* g_hue_cs;
     const HueFused* g_hue_fused;
+    uint32_t lds_m = 0u;  // 0 ("main") in every single-mask kernel — a literal there, so the test below folds away
     __device__ __forceinline__ const HueBound* hue_bounds() const { return g_hue_bounds; }
     __device__ __forceinline__ const HueBoundCs* hue_bounds_cs() const { return g_hue_cs; }
     __device__ __forceinline__ const HueFused* hue_fused() const { return g_hue_fused; }
     __device__ __forceinline__ uint32_t brightness(uint32_t m, uint32_t i) const
     {
-        if (LDS_LUT && m == 0) return lds_bright[i];
+        if (LDS_LUT && m == lds_m) return lds_bright[i];
         return g_bright[(size_t)m * RPF_CURVE_RESOLUTION + i];
     }
     __device__ __forceinline__ void hsl(uint32_t m, uint32_t i, const MaskParams& P, uint32_t& nh, float& sg,
@@ -346,7 +347,8 @@ __device__ __forceinline__ void stage_tables(const DeviceEdit& ed, MathTables* T
 {
     stage16<NT, (int)(sizeof(MathTables) / 16)>(reinterpret_cast<const uint4*>(ed.tabs), reinterpret_cast<uint4*>(T), tid);
     if (WITH_LUT)
-        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(ed.bright), reinterpret_cast<uint4*>(lut), tid);
+        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(ed.bright + (size_t)ed.lds_bright_mask * RPF_CURVE_RESOLUTION),
+                                                   reinterpret_cast<uint4*>(lut), tid);
 }
 
 // The edit chain on a pixel pair in the depth of specialisation MODE names (see the enum above).
@@ -537,7 +539,7 @@ void k_stream(const StreamArgs a)
         if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused, MULTI ? a.ed.lds_bright_mask : 0u};
     const LdsTabs tabs(0u, T, a.ed.mp[0], false);
     // the u16 band as one buffer: (rows + 4) rows of W samples (run_stream checks that it is shorter than 4 GiB)
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -804,10 +806,11 @@ void k_hp(const StreamArgs a)
     stage16<NT, (int)(TAB_BYTES / 16)>(PREC ? reinterpret_cast<const uint4*>(a.ed.fast_tabs) : reinterpret_cast<const uint4*>(a.ed.tabs),
                                        reinterpret_cast<uint4*>(smem), tid);
     if (LDS_LUT)
-        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright), reinterpret_cast<uint4*>(lut), tid);
+        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright + (size_t)(MULTI ? a.ed.lds_bright_mask : 0u) * RPF_CURVE_RESOLUTION),
+                                                   reinterpret_cast<uint4*>(lut), tid);
     if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();  // the only barrier of the kernel
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused, MULTI ? a.ed.lds_bright_mask : 0u};
     const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC>(smem, a.ed.mp[0]);
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
@@ -1814,13 +1817,25 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
             return hipErrorInvalidValue;  // a non-identity hue curve without its table: the API layer builds it
         }
     }
-    if (!lut && ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12) {  // user masks over an untouched "main"
-        if (all_hue_identity(ed) && cfg.variant != 11)
-            return run_fused<256, MODE_DEVELOP_MPH, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
+    // Launches with user masks.  There is room in LDS for ONE mask's brightness curve (128 KiB): "main"'s when it has one,
+    // else the first user mask's that has one — three L2 gathers per pixel of that mask become LDS reads (a user-mask stage
+    // costs 0.055 ms per full-frame mask, two thirds of it those gathers: profiles/r04_experiments.md).  Variant 23 (A/B):
+    // only "main"'s, as before round 4.
+    DeviceEdit edm = ed;
+    bool lutm = lut;
+    if (!lut && cfg.variant != 10 && cfg.variant != 23)
+        for (uint32_t m = 1; m < ed.num_masks && !lutm; ++m)
+            if (!(ed.mp[m].flags & MF_BRIGHT_IDENTITY)) { edm.lds_bright_mask = m; lutm = true; }
+    if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12) {  // user masks over an untouched "main" (its own curve: the identity)
+        const bool mph = all_hue_identity(ed) && cfg.variant != 11;
+        if (lutm && !hp)
+            return mph ? run_stream<1024, MODE_DEVELOP_MPH, true, OUTFMT>(cfg, d_cfa, raw, g, &edm, d_out, s)
+                       : run_stream<1024, MODE_DEVELOP_MP, true, OUTFMT>(cfg, d_cfa, raw, g, &edm, d_out, s);
+        if (mph) return run_fused<256, MODE_DEVELOP_MPH, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
         return run_fused<256, MODE_DEVELOP_MP, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
     }
-    return lut ? run_fused<1024, MODE_DEVELOP, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s)
-               : run_fused<256, MODE_DEVELOP, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
+    return lutm ? run_fused<1024, MODE_DEVELOP, true, OUTFMT>(hp, cfg, d_cfa, raw, g, &edm, d_out, s)
+                : run_fused<256, MODE_DEVELOP, false, OUTFMT>(hp, cfg, d_cfa, raw, g, &ed, d_out, s);
 }
 
 template <int OUTFMT, int PK>

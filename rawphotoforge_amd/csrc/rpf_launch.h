@@ -37,6 +37,9 @@ struct DeviceEdit {
     // binary32-only specialisation (rpf_fast.h) take it and read these tables instead of `tabs`
     uint32_t precision;
     const FastTables* fast_tabs;
+    // Which mask's brightness curve a launch that stages one in LDS (128 KiB: there is room for ONE) stages: 0 = "main"; a
+    // user mask's index when "main"'s is the identity (chosen per launch by launch_develop: the first mask that has one)
+    uint32_t lds_bright_mask;
 };
 enum EditFlags : uint32_t { EF_LEGACY_VIGNETTE = 1u, EF_DECODE_INPUT = 2u };
 
