@@ -1823,7 +1823,9 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     // only "main"'s, as before round 4.
     DeviceEdit edm = ed;
     bool lutm = lut;
-    if (!lut && cfg.variant != 10 && cfg.variant != 23)
+    // (with the curve in LDS a CU runs one 1024-thread workgroup, four waves per SIMD instead of five: worth it while the
+    // staged curve is a fair share of all the masks' gathers — measured up to 8 masks; at 16 it loses 10 %)
+    if (!lut && cfg.variant != 10 && cfg.variant != 23 && ed.num_masks <= 8)
         for (uint32_t m = 1; m < ed.num_masks && !lutm; ++m)
             if (!(ed.mp[m].flags & MF_BRIGHT_IDENTITY)) { edm.lds_bright_mask = m; lutm = true; }
     if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12) {  // user masks over an untouched "main" (its own curve: the identity)

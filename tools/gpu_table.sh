@@ -9,7 +9,9 @@ print('%-44s MP/s %9.1f  step %.4f ms  kernel avg %.4f min %.4f  frac %.4f' % ('
 rm -f $OUT/table.txt
 run --workload demosaic
 for p in D S G V T; do run --workload develop --params $p; done
+for p in D S G V T; do run --workload develop --params $p --precision fast; done   # RPF_PRECISION_FAST specialisation (round 4)
 run --workload develop --data N
+run --workload develop --data N --precision fast
 run --workload develop_packed
 run --workload develop_packed --pack mipi
 run --workload unpack
