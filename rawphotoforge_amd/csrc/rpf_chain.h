@@ -486,7 +486,11 @@ RPF_HD float dot3_fast(float c0, float c1, float c2, float x, float y, float z)
 // hue_fraction_fast) and the reference rounds its angle to binary32 (2.4e-7 rad at 2 pi), so the two differ by up to
 // C 3e-7, the size of the other roundings of this mode.  Saturation gains scale (a, b), lightness gains L, as before; a
 // mask with saturation / lightness CURVES still needs the index for its look-up (the full position, wave-uniform branch).
-template <int N, int STATIC_FLAGS = -1, bool HUE_ROT = false, class Params, class Luts, class Tabs>
+// HUE_TAB (the caller's promise: ONE mask, with hue / saturation / lightness curves, whose fused hue table exists —
+// rpf_math.h HueFused, built per editor for the exact kernels): the index comes from hue_position_fast, and cos / sin of the
+// hue the curve maps it to and both gains are read from the table entry's 16 data bytes (the exact values; the boundary
+// half of the entry is not touched) instead of a curve gather, two quotients and sincos_hue_fast.
+template <int N, int STATIC_FLAGS = -1, bool HUE_ROT = false, bool HUE_TAB = false, class Params, class Luts, class Tabs>
 RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N], const Params& mp,
                             uint32_t num_masks, const Luts& luts, const Tabs& T)
 {
@@ -559,14 +563,27 @@ RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const u
             L[n] = on ? L[n] * light_gain : L[n];
         }
     };
-    oklch_stage(0u, true);
-    for (uint32_t m = 1; m < num_masks; ++m)
-        if ((any_active >> m) & 1u) oklch_stage(m, false);
+    float tcs[N], tsn[N];
+    if constexpr (HUE_TAB) {
+        static_assert(!HUE_ROT, "a hue curve: the builtin route");
+        for (int n = 0; n < N; ++n) {
+            const HueFused* e = luts.hue_fused() + (uint32_t)hk[n];
+            tcs[n] = e->cs; tsn[n] = e->sn;
+            C[n] = C[n] * e->sat_gain;
+            L[n] = L[n] * e->light_gain;
+        }
+    } else {
+        oklch_stage(0u, true);
+        for (uint32_t m = 1; m < num_masks; ++m)
+            if ((any_active >> m) & 1u) oklch_stage(m, false);
+    }
 
     // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336)
     for (int n = 0; n < N; ++n) {
         float oa, ob;
-        if constexpr (HUE_ROT) {
+        if constexpr (HUE_TAB) {
+            oa = C[n] * tcs[n]; ob = C[n] * tsn[n];
+        } else if constexpr (HUE_ROT) {
             const float eps = hue_fraction_fast(Bq[n], A[n]) * RPF_K_HUE_STEP_F;
             oa = __builtin_fmaf(Bq[n], eps, A[n]) * C[n];
             ob = __builtin_fmaf(-A[n], eps, Bq[n]) * C[n];

@@ -395,9 +395,9 @@ __device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (
     } else if (MODE == MODE_DEVELOP_1H) {
         if (mainv) edit_chain_fast<2, -1, true>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
         else edit_chain_fast<2, -1, true>(r, gg, b, active, ed.mp, 1u, luts, T);
-    } else if (mode_single(MODE)) {
-        if (mainv) edit_chain_fast<2>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
-        else edit_chain_fast<2>(r, gg, b, active, ed.mp, 1u, luts, T);
+    } else if (mode_single(MODE)) {  // _1: a hue curve — through the editor's fused hue table (HUE_TAB)
+        if (mainv) edit_chain_fast<2, -1, false, true>(r, gg, b, active, PinnedMain{mainv}, 1u, luts, T);
+        else edit_chain_fast<2, -1, false, true>(r, gg, b, active, ed.mp, 1u, luts, T);
     } else if (MODE == MODE_DEVELOP_MPH) {
         edit_chain_fast<2, (int)MF_PRISTINE, true>(r, gg, b, active, LdsMaskParams{ed.mp, lds_mp}, ed.num_masks, luts, T);
     } else if (MODE == MODE_DEVELOP_MP) {
@@ -1074,20 +1074,25 @@ struct TexFetch {
 
 // SINGLE: 0 = any number of masks, 1 = only "main", 2 = only "main" with an identity hue curve (HUE_DIRECT),
 // 3 = only a pristine "main" (MF_PRISTINE known at compile time; sincos_hue as in 1)
-template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE>
+//         5 (PREC = 1 only) = only "main", without a hue curve: the rotation form of edit_chain_fast
+// PREC: 0 = exact (rpf_math.h), 1 = RPF_PRECISION_FAST (rpf_fast.h; SINGLE 3, 5 or 1, no lens resample, active flavour)
+template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE, int PREC = 0>
 __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    MathTables* T = reinterpret_cast<MathTables*>(smem);
-    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
+    constexpr uint32_t TAB_BYTES = TabsOf<PREC>::BYTES;
+    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + TAB_BYTES);
     const int tid = threadIdx.x;
-    constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
+    constexpr uint32_t LDS_MP = TAB_BYTES + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     assert_lds_base(smem);
-    stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
+    stage16<NT, (int)(TAB_BYTES / 16)>(PREC ? reinterpret_cast<const uint4*>(a.ed.fast_tabs) : reinterpret_cast<const uint4*>(a.ed.tabs),
+                                       reinterpret_cast<uint4*>(smem), tid);
+    if (LDS_LUT)
+        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright), reinterpret_cast<uint4*>(lut), tid);
     if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
-    const LdsTabs tabs(0u, T, a.ed.mp[0], true);
+    const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC>(smem, a.ed.mp[0]);
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
     const uint32_t stride = gridDim.x * NT * 2;
@@ -1188,7 +1193,11 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         }
         if (!SINGLE && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
-        if (SINGLE == 3)
+        if constexpr (PREC == 1) {
+            if (SINGLE == 3) edit_chain_fast<2, (int)MF_PRISTINE, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+            else if (SINGLE == 5) edit_chain_fast<2, -1, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+            else edit_chain_fast<2, -1, false, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);  // a hue curve: the fused hue table
+        } else if (SINGLE == 3)
             edit_chain<2, 0, (int)MF_PRISTINE>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         else if (SINGLE == 2)
             edit_chain<2, 1>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
@@ -1798,6 +1807,7 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
         if (ed.mp[0].flags & MF_HUE_IDENTITY)  // no hue curve: the chain needs neither chroma nor angle (edit_chain_fast's HUE_ROT)
             return lut ? run_hp<1024, MODE_DEVELOP_1H, true, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s)
                        : run_hp<1024, MODE_DEVELOP_1H, false, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
+        if (!ed.hue_fused) return hipErrorInvalidValue;  // a hue curve without its table: the API layer builds it
         return lut ? run_hp<1024, MODE_DEVELOP_1, true, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s)
                    : run_hp<1024, MODE_DEVELOP_1, false, OUTFMT, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
     }
@@ -1943,13 +1953,13 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
 #endif  // RPF_TU != 2
 
 #if RPF_TU != 1
-template <bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE>
+template <bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE, int PREC = 0>
 static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
 {
     constexpr int NT = LDS_LUT ? 1024 : 256;
-    const size_t lds = sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
+    const size_t lds = TabsOf<PREC>::BYTES + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
                        (SINGLE == 0 ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
-    auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT, SINGLE>;
+    auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT, SINGLE, PREC>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     const size_t npix = (size_t)a.g.rows * a.g.width;
@@ -1973,6 +1983,15 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
 {
     const bool lut = needs_lds_lut(a.ed);
     const bool lens = a.ed.lens_strength != 0.0f;
+    // RPF_PRECISION_FAST: the reference's own pass with the binary32-only chain (rpf_fast.h) — "main" alone, no lens
+    // resample, the active shader flavour; every other launch computes the exact chain
+    if (a.ed.precision == 1u && a.ed.fast_tabs && a.ed.num_masks == 1 && !lens && a.ed.flags == 0 && cfg.variant == 0) {
+        if (a.ed.mp[0].flags == MF_PRISTINE) return run_apply<false, false, OUTFMT, 3, 1>(cfg, a, s);
+        if (a.ed.mp[0].flags & MF_HUE_IDENTITY)
+            return lut ? run_apply<true, false, OUTFMT, 5, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 5, 1>(cfg, a, s);
+        if (!a.ed.hue_fused) return hipErrorInvalidValue;  // a hue curve without its table: the API layer builds it
+        return lut ? run_apply<true, false, OUTFMT, 1, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 1, 1>(cfg, a, s);
+    }
     if (a.ed.num_masks == 1) {  // "main" only (the common case): per-mask loops and mask-plane reads compiled out
         // (HUE_DIRECT, SINGLE == 2, is not used here: with this kernel's 16-B/px input stream the 32-byte table read
         // costs more than sincos_hue saves — D 0.234 -> 0.249 ms)

@@ -174,6 +174,29 @@ def test_fast_develop_every_cfa_layout_and_output_format(gpu):
         assert np.array_equal(rgb, np.asarray(ed.rgba(), np.float32).reshape(96, 200, 4)[..., :3])
 
 
+@pytest.mark.parametrize("pname", ["D", "S", "G", "T"])
+def test_fast_rgba_pass_against_the_oracle(gpu, pname):
+    """The reference's own pass (RGBA32F -> RGBA32F, wgsl main) in the fast precision: an editor created from linear RGB,
+    three output layouts; bounds against the oracle's apply."""
+    rng = np.random.default_rng(31)
+    h, w = 120, 333
+    rgb = rng.random((h, w, 3), dtype=np.float32) * np.float32(1.2) - np.float32(0.05)
+    p = util.oracle_params(syn.PARAM_SETS[pname])
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, rgb.reshape(-1), h, w)
+    util.configure_editor(ed, p)
+    ed.set_precision(R.PRECISION_FAST)
+    ed.apply_adjustments()
+    img = np.concatenate([rgb, np.ones((h, w, 1), np.float32)], 2)
+    want = O.apply(img, [p])
+    got = ed.rgba()
+    _assert_fast_bounds(got, want, pname, flip_bound=3e-2 if pname == "G" else 4e-3)
+    u8 = ed.to_rgb_array3_u8()
+    assert np.abs(u8.astype(np.int32) - O.rgba_to_rgb_u8(want).astype(np.int32)).max() <= 1
+    ed.set_precision(R.PRECISION_EXACT)
+    ed.apply_adjustments()
+    assert np.array_equal(np.asarray(ed.rgba(), np.float32).view(np.uint32), want.view(np.uint32))
+
+
 def test_fast_falls_back_to_the_exact_chain_where_it_has_no_specialisation(gpu):
     """User masks: no binary32 specialisation — the launch computes the exact chain (bit-identical to the oracle)."""
     cfa = util.bayer_natural(64, 96)

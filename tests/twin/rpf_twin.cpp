@@ -242,12 +242,21 @@ void twin_edit_chain_fast(const float* rgb, size_t npix, const rpf::MaskParams* 
     bool all_hue_identity = true;
     for (uint32_t m = 0; m < num_masks; ++m) all_hue_identity = all_hue_identity && (mp[m].flags & rpf::MF_HUE_IDENTITY);
     all_hue_identity = all_hue_identity && allow_rot;
+    std::vector<rpf::HueFused> store;
+    if (num_masks == 1 && !(mp[0].flags & rpf::MF_HUE_IDENTITY) && allow_rot) {  // as k_build_hue_fused builds it
+        store.resize(RPF_CURVE_RESOLUTION);
+        for (uint32_t j = 0; j < RPF_CURVE_RESOLUTION; ++j)
+            store[j] = rpf::hue_fused_entry(hue_bounds_tab()[j], HostLuts::fetch(hue, 0, j), HostLuts::fetch(sat, 0, j),
+                                            HostLuts::fetch(light, 0, j), mp[0], tabs().sc);
+        L.fused = store.data();
+    }
 #pragma omp parallel for
     for (long long i = 0; i < (long long)npix; ++i) {
         float r[1] = {rgb[i * 3]}, g[1] = {rgb[i * 3 + 1]}, b[1] = {rgb[i * 3 + 2]};
         const uint32_t act[1] = {active};
         // as the kernels choose: without a hue curve on any mask, the rotation form (edit_chain_fast's HUE_ROT)
         if (all_hue_identity) rpf::edit_chain_fast<1, -1, true>(r, g, b, act, mp, num_masks, L, T);
+        else if (L.fused) rpf::edit_chain_fast<1, -1, false, true>(r, g, b, act, mp, num_masks, L, T);   // one mask: its fused hue table
         else rpf::edit_chain_fast<1>(r, g, b, act, mp, num_masks, L, T);
         rgba_out[i * 4] = r[0]; rgba_out[i * 4 + 1] = g[0]; rgba_out[i * 4 + 2] = b[0]; rgba_out[i * 4 + 3] = 1.0f;
     }
