@@ -75,24 +75,17 @@ def main():
                          "C call per step); torch = torch.distributed batch_isend_irecv from Python (tiles.BandDeveloper, round "
                          "2's path); auto = rccl, falling back to torch if the library's communicator cannot be created on "
                          "every rank (always torch under --backend gloo)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="N > 1: hide the exchange behind the interior rows (side stream + one edge-rows launch) instead of "
-                         "exchange-then-one-launch; slower at these band sizes on the one-GPU rehearsal "
-                         "(profiles/r03_host_overhead.txt), kept for larger frames")
-    ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility")
     ap.add_argument("--halo", default="step", choices=["step", "once"],
                     help="N > 1: step (default) = every step is a NEW frame: its halo rows are exchanged in every step; once = an "
                          "editing session on ONE resident frame, the reference's own use (the image is loaded once, then "
                          "apply_adjustments runs per slider move, photo-editor-web/src/lib.rs:198): the halo rows are exchanged "
                          "before the first step and every step is the band's launch alone (RPF_SHARD_NO_EXCHANGE).  Not the "
                          "headline: stated in config.workload")
-    ap.add_argument("--schedule", default="auto", choices=["auto", "pingpong", "ahead", "serial", "overlap"],
-                    help="N > 1, per step and rank: ahead = the exchange of step k + 1 is enqueued on the library's side stream "
-                         "(by its exchange thread) beside the kernel of step k — two band buffers, rpf_shard_exchange_ahead; "
-                         "serial = exchange, then one launch, on one stream; overlap = --overlap; pingpong = TWO step pipelines that "
-                         "share nothing — two RCCL communicators (two rpf_shards), two streams, two band buffers, each shard's own "
-                         "thread enqueuing its steps (rpf_shard_develop_async), frames alternating between them: one frame's "
-                         "exchange and launch latency run beside the other frame's kernel without a cross-stream dependency.  "
+    ap.add_argument("--schedule", default="auto", choices=["auto", "pingpong", "serial"],
+                    help="N > 1, per step and rank: serial = exchange, then one launch, on one stream (rpf_shard_develop); pingpong = TWO "
+                         "step pipelines that share nothing — two RCCL communicators (two rpf_shards), two streams, two band buffers, "
+                         "each shard's own thread enqueuing its steps (rpf_shard_develop_async), frames alternating between them: one "
+                         "frame's exchange and launch latency run beside the other frame's kernel without a cross-stream dependency.  "
                          "auto (default) = serial for the headline line — the one schedule whose every ordering is a stream order — and, "
                          "when the library's two communicators exist, the same K steps again as pingpong, reported under "
                          "secondary.pingpong (a stall there ends at the library's deadline with the serial line intact)")
@@ -177,7 +170,7 @@ def main():
     # ---- who exchanges the halos at N > 1 -------------------------------------------------------------------------
     exchange_note, shard, shard_b = None, None, None
     # the pingpong schedule's second communicator — only where it will be used: an idle communicator is not free
-    want_two = (args.schedule in ("auto", "pingpong") and not args.overlap and args.halo == "step"
+    want_two = (args.schedule in ("auto", "pingpong") and args.halo == "step"
                 and args.workload in ("develop", "develop_packed"))
     if rehearse:
         shard = R.Shard(gpu, None, 0, 1)
@@ -223,7 +216,7 @@ def main():
             exchange_note = "torch.distributed batch_isend_irecv from Python (tiles.BandDeveloper)" + (
                 f" — fallback, the library's communicator failed: {err}" if err else "")
 
-    schedule = "overlap" if args.overlap else args.schedule
+    schedule = args.schedule
     halo_once = sharded and args.halo == "once"
     if halo_once:
         if args.workload not in ("develop", "develop_packed") or schedule not in ("auto", "serial"):
@@ -233,16 +226,14 @@ def main():
     also_pingpong = schedule == "auto" and lib_sched_ok and shard_b is not None and not halo_once
     if schedule == "auto":
         schedule = "serial"
-    if schedule in ("ahead", "pingpong") and not lib_sched_ok:
-        raise SystemExit(f"--schedule {schedule} needs the library's communicator (N > 1, --exchange rccl) and a fused develop workload")
-    args.overlap = schedule == "overlap"
+    if schedule == "pingpong" and not lib_sched_ok:
+        raise SystemExit("--schedule pingpong needs the library's communicator (N > 1, --exchange rccl) and a fused develop workload")
 
     def make_developer(cfgfn, packed=None, lane_shard=None):
         if sharded and shard is not None:
-            return tiles.ShardedDeveloper(gpu, W, frame_h, y0, rows, praw, cfgfn, shard=lane_shard or shard, packed=packed,
-                                          overlap=args.overlap)
+            return tiles.ShardedDeveloper(gpu, W, frame_h, y0, rows, praw, cfgfn, shard=lane_shard or shard, packed=packed)
         return tiles.BandDeveloper(gpu, W, frame_h, y0, rows, praw, cfgfn, rank, world if sharded else 1,
-                                   overlap=args.overlap, packed=packed)
+                                   overlap=False, packed=packed)
 
     ed = R.PhotoEditor.for_tile(gpu, W, frame_h, y0, rows)
     configure(ed)
@@ -303,16 +294,6 @@ def main():
                                      True, pp_streams[lane].cuda_stream, timed=e is not None)
             nstep[0] += 1
             return
-        if args.workload in ("develop", "develop_packed") and schedule == "ahead":
-            # the next step's exchange first (side stream, beside this step's kernel), then this step's band, whose own
-            # exchange was enqueued one step ago: K steps = K exchanges + K launches, as in the serial schedule
-            d, bufs = (dev, ahead_bands) if args.workload == "develop" else (dev_packed, ahead_packed)
-            k = nstep[0]
-            d.exchange_ahead(bufs[(k + 1) & 1], after_develop=True)   # the bands are resident: no upload to order after
-            d.step(bufs[k & 1], out, out_fmt if args.workload == "develop" else R.OUT_RGBA_F32,
-                   out_bpp if args.workload == "develop" else 16, True, e)
-            nstep[0] += 1
-            return
         if args.workload == "develop":   # N > 1: halo exchange + band, one call
             dev.step(band, out, out_fmt, out_bpp, not halo_once, e)
             return
@@ -334,15 +315,6 @@ def main():
             ed.dev_apply(lin.data_ptr(), out.data_ptr(), R.OUT_RGBA_F32, stream)
         if e:
             e[1].record()
-
-    ahead_bands = ahead_packed = None
-    if schedule == "ahead":   # two band buffers with the same frame; the first step's exchange goes out before any step
-        if args.workload == "develop":
-            ahead_bands = (band, band.clone())
-            dev.exchange_ahead(ahead_bands[0])
-        else:
-            ahead_packed = (packed_band, packed_band.clone())
-            dev_packed.exchange_ahead(ahead_packed[0])
 
     if halo_once:   # the session's one exchange: with the frame's upload, not with every edit
         if args.workload == "develop":
@@ -396,11 +368,6 @@ def main():
     if world > 1:                          # brackets the region but its own latency (a collective: ~0.1 ms, a fifth of 20
         dist.barrier()                     # steps on a 500-row band) is not part of any rank's K steps
     torch.cuda.synchronize()
-    if schedule == "ahead":   # the exchange that the last timed step sent ahead: consumed by one untimed step
-        k = nstep[0]
-        (dev if args.workload == "develop" else dev_packed).step(
-            (ahead_bands if args.workload == "develop" else ahead_packed)[k & 1], out, R.OUT_RGBA_F32, 16, True, None)
-        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -525,13 +492,10 @@ def main():
                             "step is the band's launch alone (not the headline mode: --halo step exchanges in every step)"
                             if halo_once else
                             ", 2-row halo exchange per step, " + {
-                             "overlap": "hidden behind the interior rows (edge rows launched after it)",
                              "serial": "then one launch over the band",
                              "pingpong": "inside each of TWO independent step pipelines (two RCCL communicators with a thread each, "
                                          "two streams, two band and output buffers; frames alternate): one frame's exchange runs "
                                          "beside the other frame's kernel; every step is one exchange + one launch",
-                             "ahead": "enqueued one step ahead on the library's side stream (two band buffers: the exchange "
-                                      "of step k+1 runs beside the kernel of step k; every step is one exchange + one launch)",
                          }[schedule] if sharded else "")),
             "mode": mode, "schedule": (("none (halo once)" if halo_once else schedule) if sharded else None), "input_resident": "hbm" if batch else "infinity_cache",
             "variant": args.variant, "precision": args.precision, "out": args.out, "preheat_steps": preheat_steps,
@@ -540,8 +504,6 @@ def main():
             "kernel_timing": (f"HIP-event pairs around {len(kern_ms) if kern_ms else (tn[0][0] + tn[1][0])} of the {args.steps} timed "
                               + ("launches, by their own start / completion signals (hipExtLaunchKernelGGL events inside "
                                  "rpf_shard_develop_async; the exchange is a kernel of RCCL's in front of each)" if schedule == "pingpong" else
-                                 "steps (the wait for the exchange sent one step earlier + the launch of one rpf_shard_develop call)"
-                                 if whole_step_events and schedule == "ahead" else
                                  "steps (exchange + launches of one rpf_shard_develop call)" if whole_step_events else
                                  "steps (prefetch pass + launch)" if batch else "launches") + f" (every {stride_ev}th)"),
             "world_size": dist.get_world_size() if world > 1 else 1,

@@ -297,38 +297,26 @@ int rpf_editor_create_for_tile(rpf_processor* p, const rpf_tile* tile, rpf_edito
  * photo-editor-web/src/lib.rs:198, photo-editor-godot/src/lib.rs:257-271) when a frame is cut into contiguous row bands, one
  * per process and GPU: with lens_distortion = 0 a pixel needs its own sample and a 5x5 CFA neighbourhood, so a band needs
  * the two Bayer rows above and below it from its neighbours and nothing else.  An rpf_shard is one rank's end of that
- * exchange: an RCCL communicator (librccl is loaded at rpf_shard_create, not linked: a single-GPU host never touches it),
- * a side stream, a few events and (from the first rpf_shard_exchange_ahead / rpf_shard_develop_async on) a thread of its
- * own that makes the RCCL calls.  One call per frame, rpf_shard_develop, enqueues the whole step and returns.  By default
- * that is, on `stream`: ncclGroupStart, ncclSend / ncclRecv of the 2-row halos with the ranks above and below, ncclGroupEnd,
- * then the fused kernel over the band.  With RPF_SHARD_OVERLAP the exchange (xGMI latency, not bandwidth: 2 x 2 x width
- * bytes per direction) hides behind the rows that need no halo:
- *
- *     stream:  gate ----> fused kernel, interior rows (they read no halo row) ------------------> wait(done)
- *     side:    wait(gate) -> the same ncclGroup -> fused kernel, the band's first and last 8 rows (one launch) -> done
- *
- * which pays two cross-stream dependencies per step: measured on one MI355X they cost more than the exchange of a
- * 6000 x 500 or 12000 x 1000 band, hence not the default; it is there for larger bands.  The band
- * buffer has the layout of rpf_dev_develop: (rows + 4) rows, row r = frame row y0 - 2 + r; the exchange writes rows 0, 1
- * and rows + 2, rows + 3 (never at a frame edge: the kernel mirrors there) and sends rows 2, 3 and rows, rows + 1.  The
- * editor is the band's (rpf_editor_create_for_tile with the band's y0 / rows; masks are band-sized).  Bands shorter than
- * 32 rows are always developed by one launch after the exchange.  lens_distortion != 0 does not shard (whole-frame resample):
- * refused, as by rpf_dev_develop.
+ * exchange: an RCCL communicator (librccl is loaded at rpf_shard_create, not linked: a single-GPU host never touches it)
+ * and (from the first rpf_shard_develop_async on) a thread of its own that makes the RCCL calls.  One call per frame,
+ * rpf_shard_develop, enqueues the whole step on `stream` and returns: ncclGroupStart, ncclSend / ncclRecv of the 2-row halos
+ * with the ranks above and below, ncclGroupEnd, then the fused kernel over the band.  (Rounds 2-3 also carried two schedules
+ * that hide the exchange behind cross-stream dependencies — interior / edge rows on a side stream, and the exchange one
+ * frame ahead; measured on one MI355X both lose to what follows at every band size, DESIGN.md section 6, and round 4 removed
+ * them.)  The band buffer has the layout of rpf_dev_develop: (rows + 4) rows, row r = frame row y0 - 2 + r; the exchange
+ * writes rows 0, 1 and rows + 2, rows + 3 (never at a frame edge: the kernel mirrors there) and sends rows 2, 3 and rows,
+ * rows + 1.  The editor is the band's (rpf_editor_create_for_tile with the band's y0 / rows; masks are band-sized).
+ * lens_distortion != 0 does not shard (whole-frame resample): refused, as by rpf_dev_develop.
  *
  * rpf_shard_unique_id: ncclGetUniqueId — call on ONE rank and hand the 128 bytes to the others (any channel: a file, a
  * socket, MPI, torch.distributed).  rpf_shard_create is collective (ncclCommInitRank): every rank of `world` calls it with
  * the same id.  world = 1 is valid and needs no id (NULL): no communicator, rpf_shard_develop is a plain launch unless
  * neighbours are set.  rpf_shard_set_neighbours overrides the ranks above / below (default rank - 1 / rank + 1, -1 = frame
  * edge); up = down = rank makes a rank exchange with itself (its first rows land in its own top halo, its last rows in its
- * bottom halo): the one-GPU rehearsal of the whole schedule, RCCL included. */
+ * bottom halo): the one-GPU rehearsal of the whole step, RCCL included. */
 #define RPF_SHARD_ID_BYTES 128
 typedef struct rpf_shard rpf_shard;
-enum {
-    RPF_SHARD_NO_EXCHANGE = 1u, /* halo rows are already in place (the caller exchanged or pre-filled them) */
-    RPF_SHARD_OVERLAP = 2u,     /* hide the exchange behind the interior rows (side stream, one edge-rows launch) */
-    RPF_SHARD_FORCE_SPLIT = 4u  /* interior / edges schedule even without neighbours (measuring its cost on one GPU) */
-};
-enum { RPF_SHARD_AHEAD_AFTER_DEVELOP = 1u }; /* rpf_shard_exchange_ahead flags */
+enum { RPF_SHARD_NO_EXCHANGE = 1u }; /* halo rows are already in place (the caller exchanged or pre-filled them) */
 enum { RPF_SHARD_TIMED = 0x100u };           /* rpf_shard_develop_async: time this step's launch (rpf_shard_timing) */
 int rpf_shard_unique_id(uint8_t id[RPF_SHARD_ID_BYTES]);
 int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, rpf_shard** out);
@@ -338,19 +326,6 @@ int rpf_shard_set_neighbours(rpf_shard* s, int up, int down);
 int rpf_shard_info(const rpf_shard* s, int* rank, int* world, int* up, int* down, char* pci_bus_id, size_t len);
 /* the halo exchange alone, on `stream` (row_bytes = bytes of one band row; rows = band rows without the halos) */
 int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream);
-/* The same exchange on the shard's OWN side stream, ordered after what `stream` holds at the call (the band's upload, the
- * last launch that read its halo rows), and remembered: the next rpf_shard_develop of this d_band makes its launch wait
- * for it and exchanges nothing itself.  With two band buffers the exchange of frame k + 1 runs beside the kernel of
- * frame k —  ahead(b1); develop(b0); ahead(b0); develop(b1); ...  — and a neighbour that runs late costs slack instead of
- * an idle GPU.  At most 4 bands may be ahead at once; every rank must make the same sequence of
- * calls (the exchanges are matched in order, as RCCL groups are).
- * flags = RPF_SHARD_AHEAD_AFTER_DEVELOP: the band's own rows are already in place (nothing on `stream` still writes
- * them), so the exchange only has to follow the shard's most recent rpf_shard_develop launch, the last reader of this
- * buffer's halo rows.  That launch's own completion signal is then the gate and nothing is recorded on `stream`: one
- * packet less between two launches, 3-4 us per step on a 6000 x 500 band.  When the shard's last develop call was not a
- * single launch that exchanged or waited for an exchange (none yet, RPF_SHARD_NO_EXCHANGE, the split schedule) it falls
- * back to the ordering above. */
-int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream, uint32_t flags);
 /* One frame step of this rank.  bits = 0: d_band is the u16 band (row_stride ignored); bits in {10, 12, 14, 16}: packed
  * rows as in rpf_dev_develop_packed (their halo rows are packed rows too). */
 int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,

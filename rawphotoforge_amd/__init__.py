@@ -6,7 +6,7 @@ package never touches the GPU; the first call into the library does.  There is n
 """
 from ._native import (CFA_BGGR, CFA_GBRG, CFA_GRBG, CFA_RGGB, CURVE_BRIGHTNESS, CURVE_HUE, CURVE_LIGHTNESS,
                       CURVE_RESOLUTION, CURVE_SATURATION, FLAVOUR_ACTIVE, FLAVOUR_GODOT_LEGACY, MAX_MASKS, PRECISION_EXACT, PRECISION_FAST, PACK_LSB_FIRST, PACK_MIPI, PACK_MSB_FIRST, OUT_RGB_F32, OUT_RGB_U8, OUT_RGBA_F32,
-                      SHARD_AHEAD_AFTER_DEVELOP, SHARD_FORCE_SPLIT, SHARD_NO_EXCHANGE, SHARD_OVERLAP, SHARD_TIMED)
+                      SHARD_NO_EXCHANGE, SHARD_TIMED)
 from .editor import (EmptyControlPoints, FailedToReadImage, GpuComputeError, GpuInitializationError, GpuProcessor,
                      InterpolationError, InvalidArgument, InvalidCurveLength, MaskNotFound, MismatchedLengths,
                      MissingControlPoints, MissingCurveOrControlPoints, NotEnoughPoints, NotStrictlyIncreasing,

@@ -38,8 +38,7 @@ PRECISION_EXACT, PRECISION_FAST = 0, 1
 PACK_MSB_FIRST, PACK_LSB_FIRST, PACK_MIPI = 0, 1, 2
 CURVE_BRIGHTNESS, CURVE_HUE, CURVE_SATURATION, CURVE_LIGHTNESS = 0, 1, 2, 3
 SHARD_ID_BYTES = 128
-SHARD_NO_EXCHANGE, SHARD_OVERLAP, SHARD_FORCE_SPLIT = 1, 2, 4
-SHARD_AHEAD_AFTER_DEVELOP = 1
+SHARD_NO_EXCHANGE = 1
 SHARD_TIMED = 0x100
 
 
@@ -127,7 +126,6 @@ SYMBOLS = {
     "rpf_shard_set_neighbours": (C.c_int, [_vp, C.c_int, C.c_int]),
     "rpf_shard_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int), _P(C.c_int), C.c_char_p, _sz]),
     "rpf_shard_exchange": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _vp]),
-    "rpf_shard_exchange_ahead": (C.c_int, [_vp, _vp, _sz, C.c_uint32, _vp, C.c_uint32]),
     "rpf_shard_develop": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp,
                                     C.c_uint32]),
     "rpf_shard_develop_async": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _P(RawParams), _vp, C.c_int, _vp,

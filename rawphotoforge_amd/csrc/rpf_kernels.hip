@@ -494,12 +494,6 @@ struct StreamArgs {
     // PACKED input (rpf_dev_develop_packed): cfa points at bit-packed rows (any of the three orders below) instead of a u16 plane
     uint32_t bits, row_stride, row_bytes;  // sample width; bytes between rows; bytes of one row = ceil(W * bits / 8)
     uint32_t lsb;                          // 0 = MSB-first bit stream, 1 = LSB-first (little-endian), 2 = MIPI CSI-2 groups
-    // PART_EDGES launches (row-tile sharding): segments from skip_from on lie skip_pairs row pairs further down, so one
-    // launch covers the band's first and last rows and nothing in between (skip_from = ~0: no gap)
-    uint32_t skip_from, skip_pairs;
-    // k_hp only: band rows [dead_lo, dead_hi) are computed where a segment reaches them but NOT stored (PART_EDGES on a
-    // band whose first row is not an R row: its steps straddle the part's boundaries); empty by default
-    uint32_t dead_lo, dead_hi;
 };
 
 // One CFA row of a strip as the wavefront sees it: v = this lane's sample; p1 / p2 = the W+E sums at
@@ -589,7 +583,7 @@ void k_stream(const StreamArgs a)
         }
         const uint32_t seg = item / a.strips, strip = item - seg * a.strips;
         const int x0 = (int)strip * STRIP_W;
-        const int pair0 = (int)(seg * a.seg_pairs + sub + (seg >= a.skip_from ? a.skip_pairs : 0u));
+        const int pair0 = (int)(seg * a.seg_pairs + sub);
         const int npairs = min((int)sub_pairs, total_pairs - pair0);
         if (npairs <= 0) continue;  // sub-item past the end of a ragged last segment
         const int xl = x0 + lane;  // this lane's column
@@ -753,11 +747,10 @@ template <int MODE, bool LDS_LUT, int OUTFMT, bool VIGN, class Tabs>
 __device__ __forceinline__ void hp_finish(float (&r)[2], float (&gg)[2], float (&b)[2], int row, const int (&col)[2],
                                           int colF, const TileGeom& g, const DeviceEdit& ed, const DevLuts<LDS_LUT>& luts,
                                           const Tabs& T, void* out, const float (&fall)[2], uint32_t lds_mp,
-                                          uint32_t dead_lo, uint32_t dead_hi, const uint32_t (&alpha)[2], const MaskParams* mainv)
+                                          const uint32_t (&alpha)[2], const MaskParams* mainv)
 {
     const int W = (int)g.width, rows = (int)g.rows;
-    // wave-uniform: the virtual rows above / below a band, and the rows a PART_EDGES launch leaves to the interior's
-    const bool row_live = row >= 0 && row < rows && !((uint32_t)row >= dead_lo && (uint32_t)row < dead_hi);
+    const bool row_live = row >= 0 && row < rows;  // wave-uniform: false for the virtual row above / below a band
     if (VIGN) {  // wgsl:166-178; the falloff of the two pixels comes from the tile's map (DeviceEdit::vign_falloff)
         for (int k = 0; k < 2; ++k) {
             const float gain = vignette_gain_from_falloff(ed.vign_strength, fall[k]);
@@ -862,7 +855,7 @@ void k_hp(const StreamArgs a)
         }
         const uint32_t seg = item / a.strips, strip = item - seg * a.strips;
         const int x0 = (int)strip * HP_STRIP_W - a.raw.xo;  // an R column (of the frame, or the virtual column -1)
-        const int pair0 = (int)(seg * a.seg_pairs + sub + (seg >= a.skip_from ? a.skip_pairs : 0u));
+        const int pair0 = (int)(seg * a.seg_pairs + sub);
         const int npairs = min((int)sub_pairs, total_pairs - pair0);
         if (npairs <= 0) continue;
         const int xa = x0 + 2 * lane;
@@ -944,7 +937,7 @@ void k_hp(const StreamArgs a)
                 cam_to_linear(camv, t2.va, cross, diag, r[0], gg[0], b[0]);
                 cam_to_linear(camv, horiz, t2.vb, vert, r[1], gg[1], b[1]);
                 hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, fall0,
-                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha, &mainv);
+                                                       MULTI ? LDS_MP : 0xffffffffu, alpha, &mainv);
             }
             {   // row 1 (window position 3): a = G site on the B row, b = B site
                 const float s1a = t2.va + t4.va, s1b = t2.vb + t4.vb;
@@ -957,7 +950,7 @@ void k_hp(const StreamArgs a)
                 cam_to_linear(camv, vert, t3.va, horiz, r[0], gg[0], b[0]);
                 cam_to_linear(camv, diag, cross, t3.vb, r[1], gg[1], b[1]);
                 hp_finish<MODE, LDS_LUT, OUTFMT, VIGN>(r, gg, b, row + 1, col, x0 + pxF, a.g, a.ed, luts, tabs, a.out, fall1,
-                                                       MULTI ? LDS_MP : 0xffffffffu, a.dead_lo, a.dead_hi, alpha, &mainv);
+                                                       MULTI ? LDS_MP : 0xffffffffu, alpha, &mainv);
             }
             // slide the window down two rows
             w0a = t2.va; w0b = t2.vb;
@@ -1514,25 +1507,6 @@ static hipError_t check_edit(const DeviceEdit& ed)
 }
 
 #if RPF_TU != 2
-// PART_INTERIOR (rpf_launch.h): the rows of tile `g` that PART_EDGES leaves out, as a tile of their own — the first
-// 2 * EDGE_PAIRS rows and the last EDGE_PAIRS row pairs removed; skip_px = the pixels in front of it (input rows, output
-// pixels and the mask-bit plane all start that much further on).
-static size_t out_bytes(int out_format) { return out_format == OUT_RGBA_F32 ? 16 : (out_format == OUT_RGB_F32 ? 12 : 3); }
-static hipError_t interior_of(const TileGeom& g, const DeviceEdit& ed, int out_format, TileGeom& gi, DeviceEdit& edi,
-                              size_t& skip_px)
-{
-    const uint32_t total_pairs = (g.rows + 1) / 2;
-    if (g.rows < 4 * 2 * EDGE_PAIRS) return hipErrorInvalidValue;  // no interior worth a launch of its own
-    if (out_format != OUT_RGBA_F32 && out_format != OUT_RGB_F32 && out_format != OUT_RGB_U8) return hipErrorInvalidValue;
-    const uint32_t first = 2 * EDGE_PAIRS, end = 2 * (total_pairs - EDGE_PAIRS);
-    gi = TileGeom{g.width, g.height, g.y0 + first, end - first};
-    edi = ed;
-    skip_px = (size_t)first * g.width;
-    if (ed.mask_bits) edi.mask_bits = ed.mask_bits + skip_px;
-    if (ed.vign_falloff) edi.vign_falloff = ed.vign_falloff + skip_px;
-    return hipSuccess;
-}
-
 // A fused develop launch; with cfg.stop_event its completion signal is that event (no marker packet behind the kernel).
 template <class K, class A>
 static inline void launch_fused(const LaunchCfg& cfg, K kernel, uint32_t grid, int nt, size_t lds, hipStream_t s, const A& a)
@@ -1555,7 +1529,6 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
 {
     StreamArgs a;
     memset(&a, 0, sizeof(a));
-    a.skip_from = 0xffffffffu;
     a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
     a.bits = pk.bits; a.row_stride = pk.row_stride; a.lsb = pk.lsb;
     a.row_bytes = (uint32_t)(((uint64_t)g.width * pk.bits + 7) / 8);
@@ -1620,14 +1593,6 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
         }
     }
     a.nitems = items_for(a.seg_pairs);
-    if (cfg.part == PART_EDGES) {  // PART_EDGES: two segments of EDGE_PAIRS row pairs, the first and the last of the band (rpf_launch.h)
-        if (total_pairs < 2 * EDGE_PAIRS) return hipErrorInvalidValue;
-        a.seg_pairs = EDGE_PAIRS;
-        a.nitems = a.strips * 2;
-        a.skip_from = 1;
-        a.skip_pairs = total_pairs - 2 * EDGE_PAIRS;
-        whole_rounds = true;  // no tail splitting: at most one item per wave
-    }
     uint32_t grid = (a.nitems + WPB - 1) / WPB;  // demosaic only: one item per wave, the hardware balances the blocks
     a.tail_start = a.nvirt = a.nitems;
     if (MODE != MODE_DEMOSAIC) {
@@ -1655,7 +1620,6 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
 {
     StreamArgs a;
     memset(&a, 0, sizeof(a));
-    a.skip_from = 0xffffffffu;
     a.cfa = d_cfa; a.g = g; a.out = d_out; a.raw = raw;
     a.ed = *ed;
     const uint32_t bp = (g.y0 + (uint32_t)raw.yo) & 1u;
@@ -1699,17 +1663,6 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
     }
     if (!whole_rounds && items_for(16) >= 2 * cap_waves) a.seg_pairs = 16;
     a.nitems = items_for(a.seg_pairs);
-    if (cfg.part == PART_EDGES) {  // the band's first 8 rows and its last 7 or 8 (rpf_launch.h), whatever row the steps start on
-        const uint32_t tp0 = (g.rows + 1) / 2, ep = EDGE_PAIRS + bp;
-        if (tp0 < 2 * EDGE_PAIRS || total_pairs < 2 * ep) return hipErrorInvalidValue;
-        a.dead_lo = 2 * EDGE_PAIRS;
-        a.dead_hi = 2 * (tp0 - EDGE_PAIRS);
-        a.seg_pairs = ep;
-        a.nitems = a.strips * 2;
-        a.skip_from = 1;
-        a.skip_pairs = total_pairs - 2 * ep;
-        whole_rounds = true;
-    }
     uint32_t grid = (a.nitems + WPB - 1) / WPB;
     const uint32_t cap = (uint32_t)cfg.num_cus * per_cu;
     if (grid > cap) grid = cap;
@@ -1897,17 +1850,6 @@ hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, 
     if (row_stride < need) return hipErrorInvalidValue;
     if ((uint64_t)row_stride * (g.rows + 4) > 0xffffffffull) return hipErrorInvalidValue;  // 32-bit row offsets
     if (ed.lens_strength != 0.0f || ed.flags != 0) return hipErrorInvalidValue;
-    if (cfg.part == PART_INTERIOR) {
-        TileGeom gi;
-        DeviceEdit edi;
-        size_t skip_px;
-        if ((e = interior_of(g, ed, out_format, gi, edi, skip_px)) != hipSuccess) return e;
-        LaunchCfg ci = cfg;
-        ci.part = PART_ALL;
-        return launch_develop_packed(ci, d_packed + (skip_px / g.width) * row_stride, row_stride, bits, order, raw, gi, edi,
-                                     reinterpret_cast<unsigned char*>(d_out) + skip_px * out_bytes(out_format), out_format, s);
-    }
-    if (cfg.part == PART_EDGES && g.rows < 4 * EDGE_PAIRS) return hipErrorInvalidValue;
     const PackedRows pk{bits, row_stride, order};
     switch (out_format) {
     // the CSI-2 group layout is a compile-time variant of the packed row loads (as a run-time branch per sample it cost
@@ -1931,17 +1873,6 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
     if (!d_cfa || !d_out) return hipErrorInvalidValue;
     if (ed.lens_strength != 0.0f) return hipErrorInvalidValue;  // needs the resampling pass (launch_apply)
     if (ed.flags != 0) return hipErrorInvalidValue;             // the Godot-legacy flavour lives in k_apply only
-    if (cfg.part == PART_INTERIOR) {  // the rows between the two edge segments, as a tile of their own
-        TileGeom gi;
-        DeviceEdit edi;
-        size_t skip_px;
-        if ((e = interior_of(g, ed, out_format, gi, edi, skip_px)) != hipSuccess) return e;
-        LaunchCfg ci = cfg;
-        ci.part = PART_ALL;
-        return launch_develop(ci, d_cfa + skip_px, raw, gi, edi, reinterpret_cast<unsigned char*>(d_out) + skip_px * out_bytes(out_format),
-                              out_format, s);
-    }
-    if (cfg.part == PART_EDGES && g.rows < 4 * EDGE_PAIRS) return hipErrorInvalidValue;
     switch (out_format) {
     case OUT_RGBA_F32: return develop_fmt<OUT_RGBA_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
     case OUT_RGB_F32: return develop_fmt<OUT_RGB_F32>(cfg, d_cfa, raw, g, ed, d_out, s);

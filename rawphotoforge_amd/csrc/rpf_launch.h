@@ -50,17 +50,9 @@ struct TileGeom {
 
 enum OutFormat { OUT_RGBA_F32 = 0, OUT_RGB_F32 = 1, OUT_RGB_U8 = 2 };
 
-// Which rows of its tile a fused launch develops (row-tile sharding, rpf_shard.cpp).  PART_EDGES: the first
-// 2 * EDGE_PAIRS rows and everything from row 2 * ((rows + 1) / 2 - EDGE_PAIRS) on — the rows whose 5x5 neighbourhoods
-// reach the band's halo rows — in ONE launch; PART_INTERIOR: the rows in between, which read no halo row.  Together
-// they write every pixel of the tile exactly once, with the bits of a PART_ALL launch.  A tile needs 32 rows for either.
-enum RowPart { PART_ALL = 0, PART_INTERIOR = 1, PART_EDGES = 2 };
-constexpr uint32_t EDGE_PAIRS = 4;
-
 struct LaunchCfg {
     int num_cus;
     int variant;  // 0 default; see rpf_kernels.hip
-    int part = PART_ALL;  // fused develop launches only
     // fused develop launches only: an event that becomes the launch's own completion signal (hipExtLaunchKernelGGL's
     // stopEvent) — what a later cross-stream wait can name without a marker packet behind the kernel
     void* stop_event = nullptr;

@@ -3,19 +3,15 @@
 // frame is cut into row bands, one process and GPU per band.
 //
 // MI355X-first: xGMI is point-to-point and a halo is 2 rows (24-48 KB), so the exchange is latency, not bandwidth.  It is
-// one ncclGroup of neighbour sends / receives, by default on the caller's stream in front of ONE launch over the band; with
-// RPF_SHARD_OVERLAP on a high-priority side stream, issued BEFORE the interior launch so that RCCL's few workgroups get their
-// CU slots ahead of the fused kernel's persistent ones, with the rows that need the halos (first and last 8 of the band) as
-// ONE small launch behind it (measured: the two cross-stream dependencies of that schedule cost more than the exchange of a
-// 500- or 1000-row band).  Everything a step needs is enqueued by one C call: no Python, no per-step
-// allocation, no host synchronisation.  For a stream of frames rpf_shard_exchange_ahead puts the NEXT band's exchange on the
-// side stream beside this band's kernel (two band buffers): its waits are for work that finished a kernel ago, the RCCL
-// group is enqueued by a thread of the shard's own, and a neighbour that runs late costs slack, not an idle GPU.
-// And because every cross-stream dependency costs this runtime 4-13 us per step, the schedule that has none:
+// one ncclGroup of neighbour sends / receives on the step's stream in front of ONE launch over the band; everything a step
+// needs is enqueued by one C call: no Python, no per-step allocation, no host synchronisation (rpf_shard_develop).  Every
+// cross-stream dependency costs this runtime 4-13 us per step — round 3 measured the two schedules that hide the exchange
+// behind such dependencies (interior / edge rows on a side stream; the exchange one frame ahead) as losers at both band sizes
+// and round 4 removed them — so the latency-hiding schedule is the one that has none:
 // rpf_shard_develop_async hands the whole step (exchange, then launch, on the step's stream) to the shard's thread, and a
 // rank runs TWO shards — two communicators, two streams, two band buffers — with frames alternating between them: one
 // frame's exchange, launch latency and tail beside the other frame's kernel (a 6000 x 500 band in 26 us per step, what the
-// kernel alone takes; 39 with the exchange in line).
+// kernel alone takes; 39 with the exchange in line).  Every wait is bounded (rpf_shard_flush / rpf_shard_drain).
 //
 // librccl is loaded with dlopen at rpf_shard_create (world > 1, or a self-exchange rehearsal): librpf_hip.so does not
 // link it, so a single-GPU host (the reference's only configuration) never maps the 300-MB library.
@@ -133,34 +129,8 @@ struct rpf_shard {
     int rank = 0, world = 1;
     int up = -1, down = -1;  // ranks that hold the rows above / below this band; -1 = frame edge
     ncclComm_t comm = nullptr;
-    hipStream_t side = nullptr;            // exchange + edge rows (highest priority)
-    hipEvent_t gate = nullptr, done = nullptr;
-    unsigned event_flags = hipEventDisableTiming;
     char bus[32] = {0};
 
-    // Exchanges enqueued ahead of their band's develop call (rpf_shard_exchange_ahead).  RCCL's group costs the host
-    // ~16 us, more than half of a 500-row band's kernel: it is enqueued by a thread of the shard's own, so that the
-    // caller's thread pays an event record and a queue push per exchange.  `rccl_mu` serialises every use of the
-    // communicator (the worker's and the calling thread's, rpf_shard_exchange / the default rpf_shard_develop).
-    struct Ahead {
-        const void* band = nullptr;
-        size_t row_bytes = 0;
-        uint32_t rows = 0;
-        hipEvent_t gate = nullptr, ready = nullptr;
-        hipEvent_t wait_for = nullptr;  // what the side stream waits for: `gate`, or a develop launch's completion signal
-        bool pending = false;   // between rpf_shard_exchange_ahead and the develop call that consumes it
-        bool enqueued = false;  // the worker has put the exchange and `ready` on the side stream
-        int rc = 0;
-        std::string error;
-    };
-    static constexpr int kAhead = 4;
-    Ahead ahead[kAhead];
-    // Completion signals of the develop launches (hipExtLaunchKernelGGL's stopEvent), rotating: what
-    // RPF_SHARD_AHEAD_AFTER_DEVELOP gates an exchange on without a marker packet on the caller's stream.
-    static constexpr int kDone = 4;
-    hipEvent_t launch_done[kDone] = {nullptr, nullptr, nullptr, nullptr};
-    int launch_i = -1;  // the most recent one in use; -1: the last develop call left none
-    bool want_launch_signal = false;  // set by the first AFTER_DEVELOP request: a signalled launch costs ~2 us more
     // Whole steps handed to the shard's thread (rpf_shard_develop_async): the exchange and the launch, enqueued on the
     // step's stream by that thread.  Two shards (two communicators, two streams, two threads) alternating frames overlap
     // one frame's exchange, launch latency and tail with the other frame's kernel without one cross-stream dependency.
@@ -172,7 +142,7 @@ struct rpf_shard {
         hipStream_t stream;
         rpf_editor* ed;  // its `queued` count is dropped when the step has been enqueued (rpf_internal.h)
     };
-    struct Work { Ahead* ahead; Step* step; };
+    struct Work { Step* step; };
     int in_flight = 0;           // steps handed over and not yet enqueued
     // progress of the shard's thread, for the message of a wait that ran into its deadline (rpf_shard_flush)
     uint64_t steps_handed = 0, steps_enqueued = 0;
@@ -183,6 +153,8 @@ struct rpf_shard {
     std::string async_error;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;  // start / stop of the timed launches since the last rpf_shard_timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_free;
+    // `rccl_mu` serialises every use of the communicator (the shard's thread's and the calling thread's: rpf_shard_exchange,
+    // rpf_shard_develop); `mu` guards the queue and the counters
     std::mutex rccl_mu, mu;
     std::condition_variable cv;
     std::deque<Work> work;
@@ -232,11 +204,10 @@ int enqueue_exchange(rpf_shard* s, unsigned char* band, size_t row_bytes, uint32
     return RPF_OK;
 }
 
-hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream, hipEvent_t stop_event = nullptr,
+hipError_t launch_band(const BandLaunch& b, hipStream_t stream, hipEvent_t stop_event = nullptr,
                        hipEvent_t start_event = nullptr, int reserve_cus = 0)
 {
     LaunchCfg cfg = cfg_of(b.proc);
-    cfg.part = part;
     if (reserve_cus > 0 && cfg.num_cus > 4 * reserve_cus) cfg.num_cus -= reserve_cus;
     cfg.stop_event = stop_event;
     cfg.start_event = start_event;
@@ -245,15 +216,15 @@ hipError_t launch_part(const BandLaunch& b, int part, hipStream_t stream, hipEve
     return launch_develop(cfg, reinterpret_cast<const uint16_t*>(b.band), b.raw, b.geom, b.dev, b.out, b.out_format, stream);
 }
 
-// The shard's exchange thread: for every band handed over by rpf_shard_exchange_ahead, side stream <- wait(gate), the
-// RCCL group, record(ready).  Errors travel to the develop call that consumes the band (rpf_last_error is per thread).
+// The shard's thread: enqueues the steps handed over by rpf_shard_develop_async, in order.  Errors travel to rpf_shard_flush
+// (rpf_last_error is per thread).
 int run_step(rpf_shard* s, const rpf_shard::Step& t);
 
 void exchange_worker(rpf_shard* s)
 {
     (void)hipSetDevice(s->proc->device);
     for (;;) {
-        rpf_shard::Work w{nullptr, nullptr};
+        rpf_shard::Work w{nullptr};
         {
             std::unique_lock<std::mutex> lock(s->mu);
             s->cv.wait(lock, [&] { return s->stop || !s->work.empty(); });
@@ -261,7 +232,7 @@ void exchange_worker(rpf_shard* s)
             w = s->work.front();
             s->work.pop_front();
         }
-        if (w.step) {  // a whole step: exchange + launch on its stream
+        {   // a whole step: exchange + launch on its stream
             const int rc = run_step(s, *w.step);
             s->phase.store("idle");
             {   // the step's copy of the editor's table pointers is no longer needed: setters / destroy may proceed
@@ -275,17 +246,6 @@ void exchange_worker(rpf_shard* s)
             if (rc && !s->async_rc) { s->async_rc = rc; s->async_error = rpf_last_error(); }
             --s->in_flight;
             ++s->steps_enqueued;
-        } else {
-            rpf_shard::Ahead* a = w.ahead;
-            int rc = RPF_OK;
-            hipError_t he = hipStreamWaitEvent(s->side, a->wait_for, 0);
-            if (he != hipSuccess) rc = api_hip_fail(he, "hipStreamWaitEvent(side, gate)");
-            if (!rc) rc = enqueue_exchange(s, static_cast<unsigned char*>(const_cast<void*>(a->band)), a->row_bytes, a->rows, s->side);
-            if (!rc && (he = hipEventRecord(a->ready, s->side)) != hipSuccess) rc = api_hip_fail(he, "hipEventRecord(ready, side)");
-            std::lock_guard<std::mutex> lock(s->mu);
-            a->rc = rc;
-            if (rc) a->error = rpf_last_error();
-            a->enqueued = true;
         }
         s->cv.notify_all();
     }
@@ -315,7 +275,7 @@ int run_step(rpf_shard* s, const rpf_shard::Step& t)
     // starts while this kernel runs — RCCL's workgroup needs a CU of its own (the fused kernel's persistent workgroups
     // fill theirs), and a persistent workgroup that has to wait for that CU makes its whole launch late.
     static const int reserve = getenv("RPF_SHARD_ASYNC_RESERVE") ? atoi(getenv("RPF_SHARD_ASYNC_RESERVE")) : 8;
-    const hipError_t le = launch_part(t.b, PART_ALL, t.stream, ev.second, ev.first, t.exchange ? reserve : 0);
+    const hipError_t le = launch_band(t.b, t.stream, ev.second, ev.first, t.exchange ? reserve : 0);
     if (timed) {  // the pair goes back to the pool whether or not the launch took it
         std::lock_guard<std::mutex> lock(s->mu);
         (le == hipSuccess ? s->timing : s->timing_free).push_back(ev);
@@ -361,20 +321,10 @@ void rpf_shard_destroy(rpf_shard* s)
         s->worker.join();
     }
     if (s->proc && hipSetDevice(s->proc->device) == hipSuccess) {
-        if (s->side) (void)hipStreamSynchronize(s->side);
         const Rccl* R = s->comm ? rccl() : nullptr;
         if (R) (void)R->CommDestroy(s->comm);
-        if (s->gate) (void)hipEventDestroy(s->gate);
-        if (s->done) (void)hipEventDestroy(s->done);
-        for (auto& e : s->launch_done)
-            if (e) (void)hipEventDestroy(e);
         for (auto* v : {&s->timing, &s->timing_free})
             for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-        for (auto& a : s->ahead) {
-            if (a.gate) (void)hipEventDestroy(a.gate);
-            if (a.ready) (void)hipEventDestroy(a.ready);
-        }
-        if (s->side) (void)hipStreamDestroy(s->side);
     }
     if (s->proc) api_processor_unref(s->proc);
     delete s;
@@ -396,21 +346,8 @@ int rpf_shard_create(rpf_processor* p, const uint8_t* id, int rank, int world, r
     s->down = rank < world - 1 ? rank + 1 : -1;
     auto bail = [&](int rc) { rpf_shard_destroy(s); return rc; };
     hipError_t he = hipSetDevice(p->device);
-    int lo = 0, hi = 0;  // numerically lower = higher priority
-    if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (he == hipSuccess) he = hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, hi);
-    // (RPF_SHARD_EVENT_FLAGS: extra hipEventCreateWithFlags bits for the shard's events, a measurement switch.  With
-    // hipEventDisableSystemFence a step of the overlapped schedules is ~3 us shorter on one GPU — not the default: the halo
-    // rows arrive over xGMI, and whether an agent-scope fence orders them for the launch cannot be shown on one GPU.)
-    unsigned evf = hipEventDisableTiming;
-    if (const char* v = getenv("RPF_SHARD_EVENT_FLAGS")) evf |= (unsigned)strtoul(v, nullptr, 0);
-    s->event_flags = evf;
-    for (auto& e : s->launch_done)
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&e, evf);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->gate, evf);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&s->done, evf);
     if (he == hipSuccess) he = hipDeviceGetPCIBusId(s->bus, (int)sizeof(s->bus), p->device);
-    if (he != hipSuccess) return bail(api_hip_fail(he, "shard stream / events"));
+    if (he != hipSuccess) return bail(api_hip_fail(he, "shard device"));
     if (world > 1) {
         const Rccl* R = rccl();
         if (!R) return bail(rccl_missing());
@@ -454,50 +391,6 @@ int rpf_shard_exchange(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t ro
     return enqueue_exchange(s, static_cast<unsigned char*>(d_band), row_bytes, rows, (hipStream_t)stream);
 }
 
-int rpf_shard_exchange_ahead(rpf_shard* s, void* d_band, size_t row_bytes, uint32_t rows, void* stream, uint32_t flags)
-{
-    if (!s || !d_band || row_bytes == 0) return api_fail(RPF_ERR_INVALID_ARGUMENT, "null argument");
-    if (s->up < 0 && s->down < 0) return RPF_OK;  // no neighbours: the develop call has nothing to wait for
-    if (rows < 2) return api_fail(RPF_ERR_INVALID_ARGUMENT, "a band must have at least 2 rows to feed its neighbours' halos");
-    HIP_TRY(hipSetDevice(s->proc->device));
-    rpf_shard::Ahead* slot = nullptr;
-    for (auto& a : s->ahead)
-        if (a.band == d_band) slot = &a;
-    for (auto& a : s->ahead)
-        if (!slot && !a.pending) slot = &a;
-    if (!slot) return api_fail(RPF_ERR_INVALID_ARGUMENT, "too many exchanges ahead of their develop calls (4 bands at most)");
-    if (slot->pending) return api_fail(RPF_ERR_INVALID_ARGUMENT, "this band already has an exchange ahead of its develop call");
-    if (!slot->gate) HIP_TRY(hipEventCreateWithFlags(&slot->gate, s->event_flags));
-    if (!slot->ready) HIP_TRY(hipEventCreateWithFlags(&slot->ready, s->event_flags));
-    if (flags & RPF_SHARD_AHEAD_AFTER_DEVELOP) s->want_launch_signal = true;
-    if ((flags & RPF_SHARD_AHEAD_AFTER_DEVELOP) && s->launch_i >= 0) {
-        // after the shard's last develop launch, named by its own completion signal: no packet on the caller's stream
-        slot->wait_for = s->launch_done[s->launch_i];
-    } else {
-        // after what `stream` holds now: the band's upload and the last launch that read these halo rows
-        HIP_TRY(hipEventRecord(slot->gate, (hipStream_t)stream));
-        slot->wait_for = slot->gate;
-    }
-    slot->band = d_band;
-    slot->row_bytes = row_bytes;
-    slot->rows = rows;
-    slot->pending = true;
-    try {
-        std::lock_guard<std::mutex> lock(s->mu);
-        slot->enqueued = false;
-        slot->rc = 0;
-        s->work.push_back(rpf_shard::Work{slot, nullptr});
-        if (!s->worker.joinable()) s->worker = std::thread(exchange_worker, s);
-    } catch (...) {  // no memory for the queue node, or no thread to be had: nothing was handed over
-        std::lock_guard<std::mutex> lock(s->mu);
-        if (!s->work.empty() && s->work.back().ahead == slot) s->work.pop_back();
-        slot->pending = false;
-        return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: could not start the shard's exchange thread");
-    }
-    s->cv.notify_all();
-    return RPF_OK;
-}
-
 namespace {
 // Argument checks and edit-state upload shared by rpf_shard_develop and rpf_shard_develop_async; fills the launch.
 int prepare_band_launch(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stride, uint32_t bits, uint32_t order,
@@ -534,45 +427,12 @@ int rpf_shard_develop(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_stri
     size_t row_bytes = 0;
     int rc = prepare_band_launch(s, e, d_band, row_stride, bits, order, raw, d_out, out_format, b, row_bytes);
     if (rc) return rc;
+    if (flags & ~(uint32_t)RPF_SHARD_NO_EXCHANGE) return api_fail(RPF_ERR_INVALID_ARGUMENT, "rpf_shard_develop takes RPF_SHARD_NO_EXCHANGE only");
     hipStream_t cur = (hipStream_t)stream;
     unsigned char* band = static_cast<unsigned char*>(d_band);
-    const uint32_t rows = b.geom.rows;
     const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
-    const bool split = ((exchange && (flags & RPF_SHARD_OVERLAP)) || (flags & RPF_SHARD_FORCE_SPLIT)) &&
-                       rows >= 4 * 2 * EDGE_PAIRS;
-    rpf_shard::Ahead* ahead = nullptr;
-    for (auto& a : s->ahead)
-        if (a.pending && a.band == d_band) ahead = &a;
-    if (ahead) {  // the halo rows are on their way (rpf_shard_exchange_ahead): wait for them, one launch
-        ahead->pending = false;
-        {
-            std::unique_lock<std::mutex> lock(s->mu);
-            s->cv.wait(lock, [&] { return ahead->enqueued; });
-            if (ahead->rc) return api_fail(ahead->rc, ahead->error);
-        }
-        HIP_TRY(hipStreamWaitEvent(cur, ahead->ready, 0));
-        s->launch_i = s->want_launch_signal ? (s->launch_i + 1) % rpf_shard::kDone : -1;
-        HIP_TRY(launch_part(b, PART_ALL, cur, s->launch_i >= 0 ? s->launch_done[s->launch_i] : nullptr));
-        return RPF_OK;
-    }
-    if (!split) {
-        if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, cur))) return rc;
-        // with a completion signal (~2 us) where a later AFTER_DEVELOP may name this launch; otherwise that orders by `stream`
-        const bool sig = exchange && s->want_launch_signal;
-        s->launch_i = sig ? (s->launch_i + 1) % rpf_shard::kDone : -1;
-        HIP_TRY(launch_part(b, PART_ALL, cur, sig ? s->launch_done[s->launch_i] : nullptr));
-        return RPF_OK;
-    }
-    // side stream: gated on what `cur` held before this step (the band's upload, the previous step's readers of the halo
-    // rows); the exchange goes first so that RCCL's workgroups are dispatched ahead of the interior's persistent ones
-    s->launch_i = -1;  // two launches, joined on `cur`: a later AFTER_DEVELOP orders by its stream
-    HIP_TRY(hipEventRecord(s->gate, cur));
-    HIP_TRY(hipStreamWaitEvent(s->side, s->gate, 0));
-    if (exchange && (rc = enqueue_exchange(s, band, row_bytes, rows, s->side))) return rc;
-    HIP_TRY(launch_part(b, PART_INTERIOR, cur));
-    HIP_TRY(launch_part(b, PART_EDGES, s->side));  // the halo rows' reader: on the stream every exchange ahead runs on
-    HIP_TRY(hipEventRecord(s->done, s->side));
-    HIP_TRY(hipStreamWaitEvent(cur, s->done, 0));
+    if (exchange && (rc = enqueue_exchange(s, band, row_bytes, b.geom.rows, cur))) return rc;
+    HIP_TRY(launch_band(b, cur));
     return RPF_OK;
 }
 
@@ -585,9 +445,6 @@ int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t ro
     size_t row_bytes = 0;
     const int rc = prepare_band_launch(s, e, d_band, row_stride, bits, order, raw, d_out, out_format, b, row_bytes);
     if (rc) return rc;
-    for (auto& a : s->ahead)
-        if (a.pending && a.band == d_band)
-            return api_fail(RPF_ERR_INVALID_ARGUMENT, "this band has an exchange ahead: its step is rpf_shard_develop's");
     const bool exchange = !(flags & RPF_SHARD_NO_EXCHANGE) && (s->up >= 0 || s->down >= 0);
     rpf_shard::Step* t = new (std::nothrow) rpf_shard::Step{b, row_bytes, b.geom.rows, exchange, (flags & RPF_SHARD_TIMED) != 0,
                                                            (hipStream_t)stream, e};
@@ -598,7 +455,7 @@ int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t ro
     }
     try {
         std::lock_guard<std::mutex> lock(s->mu);
-        s->work.push_back(rpf_shard::Work{nullptr, t});
+        s->work.push_back(rpf_shard::Work{t});
         ++s->in_flight;
         ++s->steps_handed;
         s->last_stream = (hipStream_t)stream;
@@ -616,7 +473,6 @@ int rpf_shard_develop_async(rpf_shard* s, rpf_editor* e, void* d_band, size_t ro
         delete t;
         return api_fail(RPF_ERR_GPU_COMPUTE, "GPU compute error: could not start the shard's thread");
     }
-    s->launch_i = -1;
     s->cv.notify_all();
     return RPF_OK;
 }

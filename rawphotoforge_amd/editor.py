@@ -426,7 +426,7 @@ class PhotoEditor:
 
 class Shard:
     """One rank's end of the row-tile sharding of a frame (include/rpf.h rpf_shard_*): an RCCL communicator over the
-    ranks of the node, a side stream and two events inside librpf_hip.so.  `unique_id()` on one rank, the 128 bytes to
+    ranks of the node and (for develop_async) a thread of its own inside librpf_hip.so.  `unique_id()` on one rank, the 128 bytes to
     the others by any channel, then `Shard(gpu, id, rank, world)` on every rank (collective)."""
 
     def __init__(self, gpu_processor: GpuProcessor, unique_id: Optional[bytes], rank: int = 0, world: int = 1):
@@ -457,16 +457,9 @@ class Shard:
     def exchange(self, d_band_ptr: int, row_bytes: int, rows: int, stream: int = 0) -> None:
         _check(N.lib().rpf_shard_exchange(self._h, C.c_void_p(d_band_ptr), row_bytes, rows, C.c_void_p(stream)))
 
-    def exchange_ahead(self, d_band_ptr: int, row_bytes: int, rows: int, stream: int = 0, after_develop: bool = False) -> None:
-        """The exchange on the shard's side stream, after what `stream` holds now — or, after_develop=True
-        (RPF_SHARD_AHEAD_AFTER_DEVELOP: the band's own rows are in place), after the shard's last develop launch alone;
-        the next develop() of this band waits for it instead of exchanging (rpf_shard_exchange_ahead)."""
-        _check(N.lib().rpf_shard_exchange_ahead(self._h, C.c_void_p(d_band_ptr), row_bytes, rows, C.c_void_p(stream),
-                                                N.SHARD_AHEAD_AFTER_DEVELOP if after_develop else 0))
-
     def develop(self, editor: "PhotoEditor", d_band_ptr: int, raw, d_out_ptr: int, out_format: int = N.OUT_RGBA_F32,
                 stream: int = 0, flags: int = 0, packed=None) -> None:
-        """One frame step of this rank: exchange + interior + edges enqueued by ONE library call.
+        """One frame step of this rank: the halo exchange, then the band's launch, enqueued by ONE library call.
         packed = (bits, row_stride, order) for bit-packed band rows."""
         rp = raw if isinstance(raw, N.RawParams) else raw.to_c()
         bits, stride, order = packed if packed else (0, 0, 0)

@@ -222,16 +222,16 @@ class BandDeveloper:
 
 class ShardedDeveloper:
     """One rank's band through the library's own sharded step (include/rpf.h rpf_shard_develop): ONE C call per frame
-    enqueues the RCCL halo exchange and the band's launch — or, with overlap=True (RPF_SHARD_OVERLAP), the gate, the exchange
-    on the library's side stream, the interior launch and the single edge-rows launch.  The measured N > 1 configuration of bench.py; BandDeveloper (torch.distributed) remains as
-    the rehearsal path for gloo and as the fallback when RCCL cannot be initialised inside the library.
+    enqueues the RCCL halo exchange and the band's launch on the step's stream; step_async hands the same step to the shard's
+    own thread (rpf_shard_develop_async: two ShardedDevelopers on two shards and two streams, frames alternating, are the
+    two-pipeline schedule).  The measured N > 1 configuration of bench.py; BandDeveloper (torch.distributed) remains as the
+    rehearsal path for gloo and as the fallback when RCCL cannot be initialised inside the library.
 
     `shard`: a rawphotoforge_amd.Shard (None: a one-rank shard without neighbours is created).
     `configure(ed)`: sets up the edit state of the band's editor; `add_mask` takes band-sized masks (rows x W).
     """
 
-    def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, shard=None, packed=None,
-                 overlap=False, force_split=False):
+    def __init__(self, gpu, frame_width, frame_height, y0, rows, raw, configure, shard=None, packed=None):
         from . import _native as N
         from .editor import PhotoEditor, Shard
 
@@ -241,30 +241,17 @@ class ShardedDeveloper:
         self.w, self.rows = frame_width, rows
         self.ed = PhotoEditor.for_tile(gpu, frame_width, frame_height, y0, rows)
         configure(self.ed)
-        self.flags = (N.SHARD_OVERLAP if overlap else 0) | (N.SHARD_FORCE_SPLIT if force_split else 0)
         self._no_exchange = N.SHARD_NO_EXCHANGE
-        info = self.shard.info()
-        neighbours = info["up"] >= 0 or info["down"] >= 0
-        self.split = ((neighbours and overlap) or force_split) and rows >= 32
-        # bench.py's accounting: (row offset, rows, editor) of the launch its kernel events would bracket
-        self.parts = [(8, rows - 16, self.ed)] if self.split else [(0, rows, self.ed)]
+        self.split = False
+        # bench.py's accounting: (row offset, rows, editor) of the launch its kernel events bracket
+        self.parts = [(0, rows, self.ed)]
 
     def join(self):
-        """rpf_shard_develop joins the side stream itself: nothing to do (BandDeveloper API compatibility)."""
-
-    def exchange_ahead(self, band, stream=None, after_develop=False):
-        """Start `band`'s halo exchange now, on the library's side stream (after what the stream holds at this point, or —
-        after_develop=True, the band's own rows being in place — after the shard's last develop launch alone); the next
-        step() of this band waits for it.  With two band buffers: ahead(b1); step(b0); ahead(b0); step(b1); ..."""
-        if stream is None:
-            import torch
-            stream = torch.cuda.current_stream().cuda_stream
-        row_bytes = self.packed[1] if self.packed else self.w * 2
-        self.shard.exchange_ahead(band.data_ptr(), row_bytes, self.rows, stream, after_develop)
+        """Nothing to join: the step is stream-ordered (BandDeveloper API compatibility)."""
 
     def step_async(self, band, out, out_format=0, exchange=True, stream=None, timed=False):
         """The step handed to the shard's own thread (rpf_shard_develop_async); `stream`: a raw stream handle (default: the
-        current torch stream).  Call shard.flush() before synchronising the stream."""
+        current torch stream).  Call shard.drain(stream) (or flush()) before relying on the stream's contents."""
         from . import _native as N
         if stream is None:
             import torch
@@ -274,8 +261,7 @@ class ShardedDeveloper:
 
     def step(self, band, out, out_format=0, bytes_per_px=16, exchange=True, events=None, stream=None):
         """band: (rows + 4, W) 2-byte tensor with halo rows (packed: (rows + 4, row_stride) uint8); out: rows x W pixels.
-        `events`: optional (start, end) CUDA events recorded on the launch stream around the WHOLE step (the interior
-        launch is inside the library call, so they also cover the wait for the edge rows)."""
+        `events`: optional (start, end) CUDA events recorded on the launch stream around the WHOLE step (exchange + launch)."""
         if stream is None:
             import torch
             cur = torch.cuda.current_stream()
@@ -285,6 +271,6 @@ class ShardedDeveloper:
         if events and cur is not None:
             events[0].record(cur)
         self.shard.develop(self.ed, band.data_ptr(), self.raw, out.data_ptr(), out_format, stream,
-                           self.flags | (0 if exchange else self._no_exchange), self.packed)
+                           0 if exchange else self._no_exchange, self.packed)
         if events and cur is not None:
             events[1].record(cur)

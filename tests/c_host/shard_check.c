@@ -70,8 +70,8 @@ int main(void)
     }
     rpf_processor_destroy(p);   /* shards and editors keep the processor alive */
 
-    /* argument errors first: the split schedules and unknown flags are not the async step's */
-    CHECK(rpf_shard_develop_async(shard[0], ed[0], d_band[0], 0, 0, 0, &raw, d_out[0], RPF_OUT_RGBA_F32, stream[0], RPF_SHARD_OVERLAP) ==
+    /* argument errors first: unknown flags are refused */
+    CHECK(rpf_shard_develop_async(shard[0], ed[0], d_band[0], 0, 0, 0, &raw, d_out[0], RPF_OUT_RGBA_F32, stream[0], 2u) ==
           RPF_ERR_INVALID_ARGUMENT);
     CHECK(rpf_shard_develop_async(shard[0], ed[0], NULL, 0, 0, 0, &raw, d_out[0], RPF_OUT_RGBA_F32, stream[0], 0) == RPF_ERR_INVALID_ARGUMENT);
 

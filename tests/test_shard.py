@@ -32,10 +32,10 @@ def _band_with_halos(frame, y0, rows):
 @gpu_only
 @pytest.mark.parametrize("geom", [(6000, 4000, 8, 3, "D"), (6000, 4000, 8, 7, "S"), (12000, 8000, 8, 0, "D"),
                                   (12000, 8000, 8, 4, "S"), (300, 231, 3, 1, "G"), (300, 231, 3, 2, "S")])
-def test_split_schedule_on_prefilled_halos_equals_oracle(gpu, geom):
-    """Interior launch on the caller's stream + ONE edge launch (first and last rows) on the library's side stream,
-    halos already in place: the per-rank geometry of the 8-GPU configurations, against the oracle's rows of the
-    whole frame (the oracle computes only the band: a whole 96-MP frame would take minutes)."""
+def test_band_with_prefilled_halos_equals_oracle(gpu, geom):
+    """One rank's band through rpf_shard_develop with its halos already in place: the per-rank geometry of the 8-GPU
+    configurations, against the oracle's rows of the whole frame (the oracle computes only the band: a whole 96-MP
+    frame would take minutes)."""
     torch = pytest.importorskip("torch")
     w, h, world, rank, pname = geom
     y0, rows = tiles.split_rows(h, world)[rank]
@@ -45,22 +45,16 @@ def test_split_schedule_on_prefilled_halos_equals_oracle(gpu, geom):
     want = O.develop(frame, rp, [util.oracle_params(spec)], y0=y0, rows=rows)
     band = torch.from_numpy(_band_with_halos(frame, y0, rows).view(np.int16)).cuda()
     out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
-    sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), force_split=True)
-    assert sd.split
-    for _ in range(3):  # repeated steps: the gate / done events order the reuse of band and out
+    sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec))
+    for _ in range(3):  # repeated steps: stream order covers the reuse of band and out
         sd.step(band, out, R.OUT_RGBA_F32, exchange=False)
     torch.cuda.synchronize()
     _exact(out.cpu().numpy(), want)
-    out2 = torch.zeros_like(out)   # and equal to the single launch over the same band
-    tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec)).step(band, out2, exchange=False)
-    torch.cuda.synchronize()
-    assert torch.equal(out, out2)
 
 
 @gpu_only
-def test_split_schedule_with_user_masks_and_odd_rows(gpu):
-    """Band-sized user masks (the edge launch reads the first and last rows of the mask-bit plane, the interior
-    launch the rows in between) on bands with an odd number of rows and an odd first row."""
+def test_bands_with_user_masks_and_odd_rows(gpu):
+    """Band-sized user masks on bands with an odd number of rows and an odd first row."""
     torch = pytest.importorskip("torch")
     h, w = 207, 140
     cfa = util.bayer_uniform(h, w, seed=5)
@@ -81,8 +75,8 @@ def test_split_schedule_with_user_masks_and_odd_rows(gpu):
             util.configure_editor(e, b, "b", main=False)
         band = torch.from_numpy(_band_with_halos(cfa, y0, rows).view(np.int16)).cuda()
         out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
-        sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), configure, force_split=True)
-        assert sd.split and sd.ed.num_masks == 3
+        sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), configure)
+        assert sd.ed.num_masks == 3
         sd.step(band, out, exchange=False)
         torch.cuda.synchronize()
         _exact(out.cpu().numpy(), want[y0:y0 + rows])
@@ -90,11 +84,10 @@ def test_split_schedule_with_user_masks_and_odd_rows(gpu):
 
 @gpu_only
 @pytest.mark.parametrize("pattern", [O.CFA_RGGB, O.CFA_BGGR, O.CFA_GRBG, O.CFA_GBRG])
-def test_split_schedule_on_every_cfa_phase_and_odd_bands(gpu, pattern):
+def test_bands_on_every_cfa_phase_and_odd_first_rows(gpu, pattern):
     """The horizontal-pair kernel starts its strips on an R column and its steps on an R row: for CFA layouts that begin with
-    G or B, and for bands whose first row is odd, a strip's first column / a band's first step is virtual, and the
-    edge-rows launch's segments straddle the rows they must leave to the interior launch.  Interior + edges must still
-    write every pixel of the band exactly once, with the oracle's bits (single mask: k_hp; ragged width)."""
+    G or B, and for bands whose first row is odd, a strip's first column / a band's first step is virtual.  Every pixel
+    of the band must still be written exactly once, with the oracle's bits (single mask: k_hp; ragged width)."""
     torch = pytest.importorskip("torch")
     h, w = 211, 333
     cfa = util.bayer_uniform(h, w, seed=40 + pattern)
@@ -104,16 +97,14 @@ def test_split_schedule_on_every_cfa_phase_and_odd_bands(gpu, pattern):
     for y0, rows in ((0, 91), (91, 120), (33, 47), (64, 32), (1, 209)):
         band = torch.from_numpy(_band_with_halos(cfa, y0, rows).view(np.int16)).cuda()
         out = torch.full((rows, w, 4), -7.0, dtype=torch.float32, device="cuda")
-        sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), force_split=True)
-        assert sd.split
+        sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec))
         sd.step(band, out, exchange=False)
         torch.cuda.synchronize()
         _exact(out.cpu().numpy(), want[y0:y0 + rows])
 
 
 @gpu_only
-@pytest.mark.parametrize("overlap", [True, False])
-def test_rccl_exchange_with_itself_as_neighbour(gpu, overlap):
+def test_rccl_exchange_with_itself_as_neighbour(gpu):
     """ncclCommInitRank / ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd as rpf_shard_develop issues them, on a
     one-rank communicator whose rank is its own neighbour above and below.  The band is the middle of a frame whose
     rows above / below it are the band's own first / last two rows: the exchanged halos must reproduce the oracle's
@@ -134,62 +125,13 @@ def test_rccl_exchange_with_itself_as_neighbour(gpu, overlap):
     shard.set_neighbours(0, 0)
     info = shard.info()
     assert (info["rank"], info["world"], info["up"], info["down"]) == (0, 1, 0, 0) and ":" in info["pci_bus_id"]
-    sd = tiles.ShardedDeveloper(gpu, w, h, 2, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), shard=shard,
-                                overlap=overlap)
-    assert sd.split == overlap
+    sd = tiles.ShardedDeveloper(gpu, w, h, 2, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), shard=shard)
     for _ in range(3):
         sd.step(band, out)
     torch.cuda.synchronize()
     got_band = band.cpu().numpy().view(np.uint16)
     assert np.array_equal(got_band[:2], band_rows[:2]) and np.array_equal(got_band[-2:], band_rows[-2:])
     _exact(out.cpu().numpy(), want)
-
-
-@gpu_only
-@pytest.mark.parametrize("after_develop", [False, True])
-def test_exchange_one_frame_ahead_on_two_band_buffers(gpu, after_develop):
-    """rpf_shard_exchange_ahead: the exchange of the NEXT band goes out (side stream, the shard's exchange thread) before
-    the develop call of this one.  Two band buffers with DIFFERENT frames and garbage halos, alternating for six steps:
-    every step's output must be the oracle's for the frame in its buffer (the rank is its own neighbour: the halos are
-    the band's own first / last two rows), so an exchange that landed in the wrong buffer, too late, or not at all shows."""
-    torch = pytest.importorskip("torch")
-    w, rows = 520, 96
-    rp = util.raw_params()
-    spec = syn.PARAM_SETS["S"]
-    frames, wants, bands = [], [], []
-    for seed in (21, 22):
-        br = util.bayer_uniform(rows, w, seed=seed)
-        frame = np.concatenate([br[:2], br, br[-2:]])
-        wants.append(O.develop(frame, rp, [util.oracle_params(spec)], y0=2, rows=rows))
-        pad = np.full((rows + 4, w), 777 + seed, np.uint16)
-        pad[2:-2] = br
-        frames.append(br)
-        bands.append(torch.from_numpy(pad.view(np.int16)).cuda())
-    outs = [torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-    shard = R.Shard(gpu, None, 0, 1)
-    shard.set_neighbours(0, 0)
-    sd = tiles.ShardedDeveloper(gpu, w, rows + 4, 2, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), shard=shard)
-    sd.exchange_ahead(bands[0])
-    with pytest.raises(R.InvalidArgument):   # one exchange per band and develop call
-        sd.exchange_ahead(bands[0])
-    for k in range(6):
-        if k < 5:   # after_develop: gated on the previous step's launch itself (its completion signal), no stream marker
-            sd.exchange_ahead(bands[(k + 1) & 1], after_develop=after_develop)
-        outs[k & 1].fill_(-7.0)
-        sd.step(bands[k & 1], outs[k & 1])
-        if k in (0, 1, 4, 5):
-            torch.cuda.synchronize()
-            _exact(outs[k & 1].cpu().numpy(), wants[k & 1])
-    for b, br in zip(bands, frames):
-        got = b.cpu().numpy().view(np.uint16)
-        assert np.array_equal(got[:2], br[:2]) and np.array_equal(got[-2:], br[-2:])
-    # a band without an exchange ahead still exchanges inside its develop call
-    bands[0][:2] = 1
-    bands[0][-2:] = 1
-    sd.step(bands[0], outs[0])
-    torch.cuda.synchronize()
-    _exact(outs[0].cpu().numpy(), wants[0])
-    shard.close()
 
 
 @gpu_only
@@ -231,10 +173,10 @@ def test_two_independent_step_pipelines(gpu):
     n1, ms1 = lanes[1]["shard"].timing()
     assert (n0, n1) == (5, 1) and ms0 > 0 and ms1 > 0
     assert lanes[0]["shard"].timing() == (0, 0.0)          # counted once
-    # the split schedules are rpf_shard_develop's; a failure inside a handed-over step surfaces at flush
+    # unknown flags are refused at the call; a failure inside a handed-over step surfaces at flush
     ln = lanes[0]
     with pytest.raises(R.InvalidArgument):
-        ln["shard"].develop_async(ln["dev"].ed, ln["band"].data_ptr(), ln["dev"].raw, ln["out"].data_ptr(), flags=R.SHARD_OVERLAP)
+        ln["shard"].develop_async(ln["dev"].ed, ln["band"].data_ptr(), ln["dev"].raw, ln["out"].data_ptr(), flags=2)
     for ln in lanes:
         ln["shard"].close()
 
@@ -284,45 +226,8 @@ def test_async_pipelines_under_load(gpu):
 
 
 @gpu_only
-def test_exchange_ahead_slots_and_destroy_with_exchanges_pending(gpu):
-    """Four bands may be ahead at once, a fifth is refused; a shard destroyed while exchanges are pending lets its exchange
-    thread enqueue them, drains the side stream and returns (the rank is its own neighbour, so every group completes)."""
-    torch = pytest.importorskip("torch")
-    w, rows = 256, 32
-    shard = R.Shard(gpu, None, 0, 1)
-    shard.set_neighbours(0, 0)
-    bands = [torch.full((rows + 4, w), 100 + i, dtype=torch.int16, device="cuda") for i in range(5)]
-    for b in bands[:4]:
-        shard.exchange_ahead(b.data_ptr(), w * 2, rows, torch.cuda.current_stream().cuda_stream, True)   # no launch yet: as False
-    with pytest.raises(R.InvalidArgument):
-        shard.exchange_ahead(bands[4].data_ptr(), w * 2, rows, torch.cuda.current_stream().cuda_stream)
-    shard.close()
-    torch.cuda.synchronize()
-    for i, b in enumerate(bands[:4]):   # each band's halos now hold its own rows
-        assert int(b.cpu().min()) == 100 + i and int(b.cpu().max()) == 100 + i
-
-
-@gpu_only
-def test_exchange_ahead_without_neighbours_is_a_no_op(gpu):
-    torch = pytest.importorskip("torch")
-    h, w = 64, 128
-    frame = util.bayer_uniform(h, w, seed=4)
-    rp = util.raw_params()
-    spec = syn.PARAM_SETS["D"]
-    want = O.develop(frame, rp, [util.oracle_params(spec)])
-    band = torch.from_numpy(_band_with_halos(frame, 0, h).view(np.int16)).cuda()
-    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    sd = tiles.ShardedDeveloper(gpu, w, h, 0, h, util.to_raw(rp), lambda e: syn.configure(e, spec))
-    sd.exchange_ahead(band)
-    sd.exchange_ahead(band)   # nothing is pending: no neighbours, nothing to wait for
-    sd.step(band, out)
-    torch.cuda.synchronize()
-    _exact(out.cpu().numpy(), want)
-
-
-@gpu_only
 def test_packed_band_through_the_sharded_step(gpu):
-    """12-bit LSB-first packed rows (halo rows packed too) through interior + edge launches."""
+    """12-bit LSB-first packed rows (halo rows packed too) through rpf_shard_develop."""
     torch = pytest.importorskip("torch")
     h, w, y0, rows = 160, 256, 40, 80
     frame = util.bayer_uniform(h, w, seed=3) & 0x0FFF
@@ -332,7 +237,7 @@ def test_packed_band_through_the_sharded_step(gpu):
     packed = O.pack_bayer(_band_with_halos(frame, y0, rows), 12, order=O.PACK_LSB_FIRST)
     pb = torch.from_numpy(np.ascontiguousarray(packed)).cuda()
     out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
-    sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec), force_split=True,
+    sd = tiles.ShardedDeveloper(gpu, w, h, y0, rows, util.to_raw(rp), lambda e: syn.configure(e, spec),
                                 packed=(12, packed.shape[1], R.PACK_LSB_FIRST))
     sd.step(pb, out, exchange=False)
     torch.cuda.synchronize()
@@ -368,7 +273,8 @@ def test_shard_entry_points_refuse_null_handles(hip_lib):
     assert N.last_error()
     assert lib.rpf_shard_set_neighbours(None, 0, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_exchange(None, None, 0, 0, None) == N.ERR_INVALID_ARGUMENT
-    assert lib.rpf_shard_exchange_ahead(None, None, 0, 0, None, 0) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_drain(None, None) == N.ERR_INVALID_ARGUMENT
+    assert lib.rpf_shard_set_timeout(None, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_develop_async(None, None, None, 0, 0, 0, None, None, 0, None, 0) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_flush(None) == N.ERR_INVALID_ARGUMENT
     assert lib.rpf_shard_timing(None, None, None) == N.ERR_INVALID_ARGUMENT
@@ -403,11 +309,11 @@ def test_bench_two_ranks_rehearsal_and_rccl_fallback(tmp_path):
     assert "fallback" in r["config"]["exchange"] and "ncclCommInitRank" in r["config"]["exchange"]
     assert r["value"] > 0 and abs(r["ms_per_step"] - 24.0 / r["value"] * 1e3) < 1e-2 * r["ms_per_step"]
     assert "secondary" not in r and "cpu_baseline" not in r
-    assert r["config"]["schedule"] == "serial"   # the exchange-ahead schedule needs the library's communicator
+    assert r["config"]["schedule"] == "serial"
 
 
 @gpu_only
-@pytest.mark.parametrize("schedule", ["auto", "pingpong", "ahead", "serial", "once"])
+@pytest.mark.parametrize("schedule", ["auto", "pingpong", "serial", "once"])
 def test_bench_sharded_code_path_rehearsed_on_one_gpu(schedule):
     """The N > 1 branch of bench.py with the LIBRARY's communicator (what the driver's --gpus N run takes on a node),
     rehearsed in one process: rank 4 of 8's band of THE frame, the rank its own neighbour.  The default there is two
@@ -420,7 +326,7 @@ def test_bench_sharded_code_path_rehearsed_on_one_gpu(schedule):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--preheat", "5",
            "--rehearse-ranks", "8"] + {"serial": ["--schedule", "serial"], "once": ["--halo", "once"],
-                                       "ahead": ["--schedule", "ahead"], "pingpong": ["--schedule", "pingpong"], "auto": []}[schedule]
+                                       "pingpong": ["--schedule", "pingpong"], "auto": []}[schedule]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

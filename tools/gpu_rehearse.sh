@@ -4,7 +4,7 @@ set -u
 TAG=${1:-rehearse}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
 rm -f $OUT/rehearse.txt
 for M in 2 4 8; do
-  for S in serial ahead pingpong overlap once; do
+  for S in serial pingpong once; do
     if [ $S = once ]; then SCHED="--halo once"; else SCHED="--schedule $S"; fi
     timeout -k 10 200 python bench.py --steps 400 --warmup 50 --rehearse-ranks $M $SCHED "${@:2}" 2>/dev/null | python -c "
 import sys,json

@@ -59,12 +59,9 @@ for W, H, y0, rows in ((6000, 4000, 1500, 500), (12000, 8000, 3000, 1000), (6000
         for ln in lanes:
             ln[4].close()
     run("C ABI, one launch (world 1)", tiles.ShardedDeveloper(gpu, W, H, y0, rows, raw, conf), band, out)
-    run("C ABI, interior + edges, no exchange", tiles.ShardedDeveloper(gpu, W, H, y0, rows, raw, conf, force_split=True), band, out)
     if 0 < y0 and y0 + rows < H:
         sh = R.Shard(gpu, None, 0, 1)
         sh.set_neighbours(0, 0)
-        run("C ABI, RCCL exchange with itself hidden behind the interior",
-            tiles.ShardedDeveloper(gpu, W, H, y0, rows, raw, conf, shard=sh, overlap=True), band, out)
         run("C ABI, RCCL exchange with itself, then one launch",
             tiles.ShardedDeveloper(gpu, W, H, y0, rows, raw, conf, shard=sh), band, out)
     run("torch schedule of round 2 (3 launches from Python, side stream)",
