@@ -209,8 +209,9 @@ int rpf_set_shader_flavour(rpf_editor* e, int flavour);
  *   frames: median 1-2 ulp per channel, 92-98 % of the pixels within 1e-6 and 99.6 % within 1e-5; the rest sit where the hue
  *   index steps (the hue moves by one step of the index scale there, in the reference too: within 2e-3 for the default
  *   curves; a steep per-hue curve scales that) (tests/test_fast_math.py, tests/test_gpu_fast.py).  A hint: launches that
- *   have no binary32 specialisation (user masks, packed input, the lens resample, the Godot-legacy flavour) compute the
- *   exact chain; a u16 Bayer band and the RGBA pass with only "main" have one.  Not versioned edit
+ *   have no binary32 specialisation (packed input, the lens resample, the Godot-legacy flavour, user masks with an output
+ *   layout other than RGBA32F or in the RGBA pass) compute the exact chain; a u16 Bayer band (with or without user masks)
+ *   and the RGBA pass with only "main" have one.  Not versioned edit
  *   state: takes effect at the next apply / rpf_dev_* call.  No reference counterpart (wgpu has one precision, the driver's). */
 enum { RPF_PRECISION_EXACT = 0, RPF_PRECISION_FAST = 1 };
 int rpf_set_precision(rpf_editor* e, int precision);

@@ -88,11 +88,11 @@ __device__ __forceinline__ float chain_main_light(const LdsFastTabs& T, const Ma
 template <int PREC> struct TabsOf { typedef LdsTabs type; static constexpr uint32_t BYTES = (uint32_t)sizeof(MathTables); };
 template <> struct TabsOf<1> { typedef LdsFastTabs type; static constexpr uint32_t BYTES = (uint32_t)sizeof(FastTables); };
 // the tables staged at the start of the dynamic shared block (LDS address 0)
-template <int PREC>
+template <int PREC, bool PIN = true>
 __device__ __forceinline__ typename TabsOf<PREC>::type make_lds_tabs(const unsigned char* smem, const MaskParams& main)
 {
     if constexpr (PREC == 1) return LdsFastTabs(0u, main);
-    else return LdsTabs(0u, reinterpret_cast<const MathTables*>(smem), main, true);
+    else return LdsTabs(0u, reinterpret_cast<const MathTables*>(smem), main, PIN);
 }
 // Mask parameters as the multi-mask kernels read them: "main" through the kernel-argument segment (loaded once, scalar
 // registers), a user mask's 48 bytes from a copy in LDS at byte address `lds_base` with three 16-byte reads per mask per
@@ -412,11 +412,11 @@ __device__ __forceinline__ void run_chain(float (&r)[2], float (&gg)[2], float (
 // c/s1/e1/d/v2/h2 [0] = top pixel, [1] = bottom pixel.  cx = RGGB cell column of this lane, cy_top of the top row.
 // VIGN: 0 = the launch has no vignette (code and registers compiled out), 1 = decided at run time from the pixel
 // position (generic), 2 = the caller hoisted the squared coordinates of the column and of the two rows.
-template <int MODE, bool LDS_LUT, int OUTFMT, int VIGN = 1>
+template <int MODE, bool LDS_LUT, int OUTFMT, int VIGN = 1, class Tabs = LdsTabs>
 __device__ __forceinline__ void finish_pair(const float (&c)[2], const float (&s1)[2], const float (&e1)[2],
                                             const float (&d)[2], const float (&v2)[2], const float (&h2)[2], int cx,
                                             int cy_top, const RawParamsDev& raw, const DeviceEdit& ed,
-                                            const DevLuts<LDS_LUT>& luts, const LdsTabs& T, int gx, int ry_top,
+                                            const DevLuts<LDS_LUT>& luts, const Tabs& T, int gx, int ry_top,
                                             const TileGeom& g, bool col_live, void* out, const float* cam,
                                             float vcx2 = 0.0f, float vcy2_top = 0.0f, float vcy2_bot = 0.0f,
                                             uint32_t lds_mp = 0xffffffffu)  // LDS address of the staged mask parameters
@@ -516,25 +516,34 @@ __device__ __forceinline__ RowTaps row_taps(float v, float h, bool need_p2)
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // one global_load_dword at any byte address
 
 // 256-thread builds are launched five workgroups per CU: tell the register allocator (<= 96 VGPRs)
-template <int NT, int MODE, bool LDS_LUT, int OUTFMT, int PACKED = 0, bool VIGN = false>
+// PREC = 1: RPF_PRECISION_FAST (rpf_fast.h) — launches with user masks; the tables staged are the FastTables
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, int PACKED = 0, bool VIGN = false, int PREC = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 5 : 1)))
 void k_stream(const StreamArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t TAB_BYTES = TabsOf<PREC>::BYTES;
     MathTables* T = reinterpret_cast<MathTables*>(smem);
-    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + sizeof(MathTables));
+    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + TAB_BYTES);
     const int tid = threadIdx.x;
     // the multi-mask kernels keep the masks' uniform parameters behind the tables (and the curve)
-    constexpr uint32_t LDS_MP = (uint32_t)sizeof(MathTables) + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
+    constexpr uint32_t LDS_MP = TAB_BYTES + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     constexpr bool MULTI = mode_multi(MODE);
     if (MODE != MODE_DEMOSAIC) {
         assert_lds_base(smem);
-        stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
+        if (PREC) {
+            stage16<NT, (int)(TAB_BYTES / 16)>(reinterpret_cast<const uint4*>(a.ed.fast_tabs), reinterpret_cast<uint4*>(smem), tid);
+            if (LDS_LUT)
+                stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright + (size_t)a.ed.lds_bright_mask * RPF_CURVE_RESOLUTION),
+                                                           reinterpret_cast<uint4*>(lut), tid);
+        } else {
+            stage_tables<NT, LDS_LUT>(a.ed, T, lut, tid);
+        }
         if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
         __syncthreads();  // the only barrier of the kernel
     }
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused, MULTI ? a.ed.lds_bright_mask : 0u};
-    const LdsTabs tabs(0u, T, a.ed.mp[0], false);
+    const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC, false>(smem, a.ed.mp[0]);
     // the u16 band as one buffer: (rows + 4) rows of W samples (run_stream checks that it is shorter than 4 GiB)
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
@@ -1522,7 +1531,7 @@ struct PackedRows {  // bit-packed input of the fused kernel (bits == 0: d_cfa i
     uint32_t bits, row_stride, lsb;
 };
 
-template <int NT, int MODE, bool LDS_LUT, int OUTFMT, int PACKED = 0>
+template <int NT, int MODE, bool LDS_LUT, int OUTFMT, int PACKED = 0, int PREC = 0>
 static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawParamsDev& raw, const TileGeom& g,
                              const DeviceEdit* ed, void* d_out, hipStream_t s, uint32_t seg_pairs = 0,
                              uint32_t blocks_per_cu = 0, PackedRows pk = PackedRows{0, 0, 0})
@@ -1540,14 +1549,15 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     const uint32_t total_pairs = (g.rows + 1) / 2;
     a.strips = (g.width + STRIP_W - 1) / STRIP_W;
     constexpr uint32_t WPB = NT / 64;
-    const size_t lds = MODE != MODE_DEMOSAIC ? sizeof(MathTables) + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
+    if (PREC && (!ed || !ed->fast_tabs)) return hipErrorInvalidValue;
+    const size_t lds = MODE != MODE_DEMOSAIC ? TabsOf<PREC>::BYTES + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
                                                    (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0)
                                              : 0;
     // two builds of every fused kernel: with the vignette stage (coordinates hoisted per column / per row) and
     // without it (its code and registers compiled out: the plain kernel stays under 96 VGPRs)
     const bool vign = MODE != MODE_DEMOSAIC && ed && ed->vign_strength != 0.0f;
-    auto kernel = vign ? k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED, MODE != MODE_DEMOSAIC>
-                       : k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED, false>;
+    auto kernel = vign ? k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED, MODE != MODE_DEMOSAIC, PREC>
+                       : k_stream<NT, MODE, LDS_LUT, OUTFMT, PACKED, false, PREC>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
     // persistent workgroups for the fused kernel (LDS tables staged once per workgroup), as many as are resident: it
@@ -1791,6 +1801,19 @@ static hipError_t develop_fmt(const LaunchCfg& cfg, const uint16_t* d_cfa, const
     if (!lut && cfg.variant != 10 && cfg.variant != 23 && ed.num_masks <= 8)
         for (uint32_t m = 1; m < ed.num_masks && !lutm; ++m)
             if (!(ed.mp[m].flags & MF_BRIGHT_IDENTITY)) { edm.lds_bright_mask = m; lutm = true; }
+    // RPF_PRECISION_FAST with user masks (RGBA32F output; the other layouts compute the exact chain): the column-per-lane
+    // kernel over edit_chain_fast — the rotation form when no mask has a hue curve
+    if (OUTFMT == OUT_RGBA_F32 && ed.precision == 1u && ed.fast_tabs && cfg.variant == 0 && ed.num_masks > 1) {
+        if (ed.mp[0].flags == MF_PRISTINE) {
+            if (all_hue_identity(ed))
+                return lutm ? run_stream<1024, MODE_DEVELOP_MPH, true, OUT_RGBA_F32, 0, 1>(cfg, d_cfa, raw, g, &edm, d_out, s)
+                            : run_stream<256, MODE_DEVELOP_MPH, false, OUT_RGBA_F32, 0, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
+            return lutm ? run_stream<1024, MODE_DEVELOP_MP, true, OUT_RGBA_F32, 0, 1>(cfg, d_cfa, raw, g, &edm, d_out, s)
+                        : run_stream<256, MODE_DEVELOP_MP, false, OUT_RGBA_F32, 0, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
+        }
+        return lutm ? run_stream<1024, MODE_DEVELOP, true, OUT_RGBA_F32, 0, 1>(cfg, d_cfa, raw, g, &edm, d_out, s)
+                    : run_stream<256, MODE_DEVELOP, false, OUT_RGBA_F32, 0, 1>(cfg, d_cfa, raw, g, &ed, d_out, s);
+    }
     if (ed.mp[0].flags == MF_PRISTINE && cfg.variant != 12) {  // user masks over an untouched "main" (its own curve: the identity)
         const bool mph = all_hue_identity(ed) && cfg.variant != 11;
         if (lutm && !hp)

@@ -197,21 +197,50 @@ def test_fast_rgba_pass_against_the_oracle(gpu, pname):
     assert np.array_equal(np.asarray(ed.rgba(), np.float32).view(np.uint32), want.view(np.uint32))
 
 
-def test_fast_falls_back_to_the_exact_chain_where_it_has_no_specialisation(gpu):
-    """User masks: no binary32 specialisation — the launch computes the exact chain (bit-identical to the oracle)."""
-    cfa = util.bayer_natural(64, 96)
+def test_fast_develop_with_user_masks(gpu):
+    """Launches with user masks in the fast precision (the column-per-lane kernel over edit_chain_fast): "main" pristine or
+    edited, user masks with tone sliders and a brightness curve (staged in LDS when "main" has none) or with hue curves."""
+    cfa = util.bayer_natural(96, 200)
     rp = util.raw_params()
-    ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
-    m = np.zeros((64, 96), np.float32)
-    m[:, 40:] = 1.0
-    ed.add_mask("right", m)
+    m1 = np.zeros((96, 200), np.float32)
+    m1[:, 90:] = 1.0
+    m2 = np.zeros((96, 200), np.float32)
+    m2[20:70, 30:150] = 1.0
     ps = util.params_S()
     ps.vignette = 0
-    util.configure_editor(ed, ps, mask_name="right", main=False)
+    masks = np.stack([np.ones((96, 200), np.float32), O.binarize_mask(m1), O.binarize_mask(m2)])
+    for main, second, bound in ((util.params_D(), ps, 4e-3), (util.oracle_params(syn.PARAM_SETS["T"]), ps, 4e-3),
+                                (util.params_D(), util.params_G(), 3e-2)):
+        ed = R.PhotoEditor.new_from_bayer_u16(gpu, cfa, util.to_raw(rp))
+        ed.add_mask("right", m1)
+        ed.add_mask("box", m2)
+        util.configure_editor(ed, main)
+        util.configure_editor(ed, ps, mask_name="right", main=False)
+        util.configure_editor(ed, second, mask_name="box", main=False)
+        ed.set_precision(R.PRECISION_FAST)
+        ed.apply_adjustments()
+        want = O.develop(cfa, rp, [main, ps, second], masks=masks)
+        _assert_fast_bounds(ed.rgba(), want, "masks", flip_bound=bound)
+
+
+def test_fast_falls_back_to_the_exact_chain_where_it_has_no_specialisation(gpu):
+    """Packed input has no binary32 specialisation — the launch computes the exact chain (bit-identical to the oracle)."""
+    import torch
+    h, w = 64, 96
+    frame = util.bayer_uniform(h, w, seed=3) & 0x0FFF
+    rp = O.RawParams(black=(256,) * 4, white=4095.0)
+    pad = np.zeros((h + 4, w), np.uint16)
+    pad[2:h + 2] = frame
+    packed = O.pack_bayer(pad, 12, order=O.PACK_LSB_FIRST)
+    pb = torch.from_numpy(np.ascontiguousarray(packed)).cuda()
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
     ed.set_precision(R.PRECISION_FAST)
-    ed.apply_adjustments()
-    want = O.develop(cfa, rp, [util.params_D(), ps], masks=np.stack([np.ones((64, 96), np.float32), O.binarize_mask(m)]))
-    assert np.array_equal(np.asarray(ed.rgba(), np.float32).reshape(want.shape).view(np.uint32), want.view(np.uint32))
+    ed.dev_develop_packed(pb.data_ptr(), packed.shape[1], 12, util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32,
+                          torch.cuda.current_stream().cuda_stream, R.PACK_LSB_FIRST)
+    torch.cuda.synchronize()
+    want = O.develop(frame, rp, [util.params_D()])
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
 def test_fast_develop_full_frame_statistics(gpu):
