@@ -432,12 +432,11 @@ void rpf_editor_destroy(rpf_editor* e)
 {
     if (!e) return;
     if (e->proc && hipSetDevice(e->proc->device) == hipSuccess) {
-        // steps still queued in a shard's thread hold pointers into the tables freed below; should they not get enqueued
-        // within the deadline the tables are leaked rather than freed under a kernel that may still be launched
-        const bool idle = api_editor_quiesce(e) == RPF_OK;
+        // Steps still queued in a shard's thread hold pointers into the tables freed below, and to this object.  Should they
+        // not get enqueued within the deadline (a stalled exchange), the editor is LEAKED — tables, stream and all — rather
+        // than freed under a thread that will still touch it; the caller has been told (rpf_shard_flush / _drain failed).
+        if (api_editor_quiesce(e) != RPF_OK) return;
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        if (!idle) { e->d_bright = nullptr; e->d_hsl = nullptr; e->d_masks = nullptr; e->d_mask_bits = nullptr;
-                     e->d_vign_falloff = nullptr; e->d_hue_fused_alloc = nullptr; }
         void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits,
                         e->d_vign_falloff, e->d_hue_fused_alloc};
         for (void* b : bufs)

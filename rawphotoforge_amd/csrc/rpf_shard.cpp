@@ -313,11 +313,20 @@ void rpf_shard_destroy(rpf_shard* s)
 {
     if (!s) return;
     if (s->worker.joinable()) {
+        bool idle = true;
         {
-            std::lock_guard<std::mutex> lock(s->mu);
+            std::unique_lock<std::mutex> lock(s->mu);
+            const int ms = shard_deadline_ms(s);
+            auto done = [&] { return s->in_flight == 0; };
+            if (ms > 0) idle = s->cv.wait_for(lock, std::chrono::milliseconds(ms), done);
+            else s->cv.wait(lock, done);
             s->stop = true;
         }
         s->cv.notify_all();
+        if (!idle) {  // the thread sits in a call that does not return (a stalled exchange): leave it and the shard behind
+            s->worker.detach();
+            return;
+        }
         s->worker.join();
     }
     if (s->proc && hipSetDevice(s->proc->device) == hipSuccess) {

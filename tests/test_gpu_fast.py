@@ -197,6 +197,30 @@ def test_fast_rgba_pass_against_the_oracle(gpu, pname):
     assert np.array_equal(np.asarray(ed.rgba(), np.float32).view(np.uint32), want.view(np.uint32))
 
 
+def test_fast_develop_on_row_bands(gpu):
+    """Row bands of a frame (odd first rows, every CFA phase) through the device-pointer layer in the fast precision: the
+    vignette's falloff map and the rotation form use the band's GLOBAL position; bounds against the oracle's rows."""
+    import torch
+    h, w = 211, 333
+    spec = syn.PARAM_SETS["S"]
+    for pattern in (O.CFA_RGGB, O.CFA_GBRG):
+        cfa = util.bayer_uniform(h, w, seed=50 + pattern)
+        rp = O.RawParams(cfa_pattern=pattern, black=(500, 520, 530, 510), wb=(2.1, 1.0, 1.02, 1.6))
+        want = O.develop(cfa, rp, [util.oracle_params(spec)])
+        for y0, rows in ((0, 91), (91, 120), (33, 47)):
+            pad = np.zeros((rows + 4, w), np.uint16)
+            lo, hi = max(y0 - 2, 0), min(y0 + rows + 2, h)
+            pad[lo - (y0 - 2):hi - (y0 - 2)] = cfa[lo:hi]
+            band = torch.from_numpy(pad.view(np.int16)).cuda()
+            out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+            ed = R.PhotoEditor.for_tile(gpu, w, h, y0, rows)
+            syn.configure(ed, spec)
+            ed.set_precision(R.PRECISION_FAST)
+            ed.dev_develop(band.data_ptr(), util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            _assert_fast_bounds(out.cpu().numpy(), want[y0:y0 + rows], (pattern, y0, rows))
+
+
 def test_fast_develop_with_user_masks(gpu):
     """Launches with user masks in the fast precision (the column-per-lane kernel over edit_chain_fast): "main" pristine or
     edited, user masks with tone sliders and a brightness curve (staged in LDS when "main" has none) or with hue curves."""
