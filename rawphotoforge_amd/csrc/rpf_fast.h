@@ -65,8 +65,8 @@ template <> struct FastPowCoef<POW_GAMMA> {
 };
 
 // the byte offset of x's entry inside its table
-template <int KIND>
-RPF_HD uint32_t fast_pow_offset(float x)
+template <int KIND, class TabT>
+RPF_HD uint32_t fast_pow_offset(float x, const TabT&)
 {
     using G = FastPowGeom<KIND>;
     constexpr int32_t BASE16 = (int32_t)((uint32_t)(127 + G::E0) * FAST_POW_J * 16u);
@@ -88,7 +88,25 @@ template <int KIND> RPF_HD float fast_pow_c3(const FastPowEntry*) { return FastP
 struct LdsFastPow {
     uint32_t base;
     float c3;
+    // offset = clamp(shifted pattern - sub, lo, hi), address = base + offset.  Plainly: sub = the first row's shifted pattern,
+    // lo = 0, hi = the last entry.  BIASED (fast_pow_biased): a table staged at an LDS address not below its first row's
+    // shifted pattern keeps the pattern as it is — sub = 0, the clamp's bounds move instead and base = address - first row
+    // goes into the read's immediate offset field: one instruction less per evaluation.  All five are literals after inlining.
+    int32_t sub, lo, hi;
 };
+template <int KIND>
+__device__ __forceinline__ LdsFastPow fast_pow_plain(uint32_t lds_addr, float c3)
+{
+    using G = FastPowGeom<KIND>;
+    return LdsFastPow{lds_addr, c3, (int32_t)((uint32_t)(127 + G::E0) * FAST_POW_J * 16u), 0, (G::ROWS * FAST_POW_J - 1) * 16};
+}
+template <int KIND>
+__device__ __forceinline__ LdsFastPow fast_pow_biased(uint32_t lds_addr, float c3)  // lds_addr >= the first row's shifted pattern
+{
+    using G = FastPowGeom<KIND>;
+    const int32_t first = (int32_t)((uint32_t)(127 + G::E0) * FAST_POW_J * 16u);
+    return LdsFastPow{lds_addr - (uint32_t)first, c3, 0, first, first + (G::ROWS * FAST_POW_J - 1) * 16};
+}
 __device__ __forceinline__ FastPowEntry fast_pow_read(const LdsFastPow& T, uint32_t off)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -100,6 +118,12 @@ __device__ __forceinline__ FastPowEntry fast_pow_read(const LdsFastPow& T, uint3
     return FastPowEntry{0.0f, 0.0f, 0.0f, 0.0f};  // host pass of the HIP compilation: never called
 #endif
 }
+template <int KIND>
+__device__ __forceinline__ uint32_t fast_pow_offset(float x, const LdsFastPow& T)
+{
+    const int32_t off = (((int32_t)f2bits(x) >> 14) & ~15) - T.sub;
+    return (uint32_t)(off < T.lo ? T.lo : (off > T.hi ? T.hi : off));
+}
 template <int KIND> __device__ __forceinline__ float fast_pow_c3(const LdsFastPow& T) { return T.c3; }
 #endif
 
@@ -107,7 +131,7 @@ template <int KIND, class TabT>
 RPF_HD float powc_fast(float x, const TabT& tab)
 {
     using K = FastPowCoef<KIND>;
-    const FastPowEntry e = fast_pow_read(tab, fast_pow_offset<KIND>(x));
+    const FastPowEntry e = fast_pow_read(tab, fast_pow_offset<KIND>(x, tab));
     const float t = __builtin_fmaf(x, e.r, -1.0f);  // the entry's r carries 2^-e: x r = m / (bin centre)
     float p = __builtin_fmaf(t, fast_pow_c3<KIND>(tab), K::c2);
     p = __builtin_fmaf(t, p, K::c1);
@@ -161,7 +185,7 @@ RPF_HD float hue_position_fast(float y, float x)
     float mx, mn;
     asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
     asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
-    const float q = mn * __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(mx, 0x1p-100f, 0x1p+100f));
+    const float q = mn * __builtin_amdgcn_rcpf(mx + 0x1p-100f);  // (+ 2^-100: no change to a normal mx; a = b = 0 gives q = 0, not 0 * inf)
 #else
     const float mx = ax > ay ? ax : ay;
     const float mn = ax > ay ? ay : ax;
@@ -195,7 +219,7 @@ RPF_HD float hue_fraction_fast(float y, float x)
     float mx, mn;
     asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
     asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
-    const float q = mn * __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(mx, 0x1p-100f, 0x1p+100f));
+    const float q = mn * __builtin_amdgcn_rcpf(mx + 0x1p-100f);  // (+ 2^-100: no change to a normal mx; a = b = 0 gives q = 0, not 0 * inf)
 #else
     const float mx = ax > ay ? ax : ay;
     const float mn = ax > ay ? ay : ax;

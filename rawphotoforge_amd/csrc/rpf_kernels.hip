@@ -72,9 +72,12 @@ __device__ __forceinline__ float chain_main_light(const LdsTabs& T, const MaskPa
 struct LdsFastTabs {
     LdsFastPow cbrt, gamma;
     float k_gamma_lin, k_gamma_off, k_gamma_mul, main_sat, main_light;
-    __device__ __forceinline__ LdsFastTabs(uint32_t base, const MaskParams& main)
-        : cbrt{base + (uint32_t)offsetof(FastTables, cbrt), FastPowCoef<POW_CBRT>::c3},
-          gamma{base + (uint32_t)offsetof(FastTables, gamma), FastPowCoef<POW_GAMMA>::c3},
+    // biased: `base` is FAST_TABS_BIASED_AT (k_hp's one-workgroup-per-CU launches without a curve in LDS)
+    __device__ __forceinline__ LdsFastTabs(uint32_t base, const MaskParams& main, bool biased = false)
+        : cbrt(biased ? fast_pow_biased<POW_CBRT>(base + (uint32_t)offsetof(FastTables, cbrt), FastPowCoef<POW_CBRT>::c3)
+                      : fast_pow_plain<POW_CBRT>(base + (uint32_t)offsetof(FastTables, cbrt), FastPowCoef<POW_CBRT>::c3)),
+          gamma(biased ? fast_pow_biased<POW_GAMMA>(base + (uint32_t)offsetof(FastTables, gamma), FastPowCoef<POW_GAMMA>::c3)
+                       : fast_pow_plain<POW_GAMMA>(base + (uint32_t)offsetof(FastTables, gamma), FastPowCoef<POW_GAMMA>::c3)),
           k_gamma_lin(12.92f), k_gamma_off(0.055f), k_gamma_mul(1.055f), main_sat(main.sat_gain), main_light(main.light_gain)
     {
         asm volatile("" : "+v"(cbrt.c3), "+v"(gamma.c3), "+v"(k_gamma_lin), "+v"(k_gamma_off), "+v"(k_gamma_mul), "+v"(main_sat), "+v"(main_light));
@@ -85,13 +88,20 @@ __device__ __forceinline__ float chain_k_gamma_off(const LdsFastTabs& T) { retur
 __device__ __forceinline__ float chain_k_gamma_mul(const LdsFastTabs& T) { return T.k_gamma_mul; }
 __device__ __forceinline__ float chain_main_sat(const LdsFastTabs& T, const MaskParams&) { return T.main_sat; }
 __device__ __forceinline__ float chain_main_light(const LdsFastTabs& T, const MaskParams&) { return T.main_light; }
+// Where a launch with LDS to spare stages the FastTables so that both tables lie at or above their first row's shifted bit
+// pattern (rpf_fast.h fast_pow_biased): the cube-root table's first row is pattern (127 - 22) * 32 * 16 = 53760, the gamma
+// table then starts at 53760 + 11776 = 65536 >= (127 - 9) * 32 * 16 = 60416.  70 KiB of LDS, of which the first 52.5 are unused.
+constexpr uint32_t FAST_TABS_BIASED_AT = (uint32_t)(127 + FastPowGeom<POW_CBRT>::E0) * FAST_POW_J * 16u;
+static_assert(FAST_TABS_BIASED_AT + offsetof(FastTables, gamma) >= (uint32_t)(127 + FastPowGeom<POW_GAMMA>::E0) * FAST_POW_J * 16u &&
+              FAST_TABS_BIASED_AT + offsetof(FastTables, gamma) - (uint32_t)(127 + FastPowGeom<POW_GAMMA>::E0) * FAST_POW_J * 16u < 65536u,
+              "the gamma table's bias must fit the read's 16-bit immediate offset");
 template <int PREC> struct TabsOf { typedef LdsTabs type; static constexpr uint32_t BYTES = (uint32_t)sizeof(MathTables); };
 template <> struct TabsOf<1> { typedef LdsFastTabs type; static constexpr uint32_t BYTES = (uint32_t)sizeof(FastTables); };
 // the tables staged at the start of the dynamic shared block (LDS address 0)
-template <int PREC, bool PIN = true>
+template <int PREC, bool PIN = true, bool BIASED = false>
 __device__ __forceinline__ typename TabsOf<PREC>::type make_lds_tabs(const unsigned char* smem, const MaskParams& main)
 {
-    if constexpr (PREC == 1) return LdsFastTabs(0u, main);
+    if constexpr (PREC == 1) return LdsFastTabs(BIASED ? FAST_TABS_BIASED_AT : 0u, main, BIASED);
     else return LdsTabs(0u, reinterpret_cast<const MathTables*>(smem), main, PIN);
 }
 // Mask parameters as the multi-mask kernels read them: "main" through the kernel-argument segment (loaded once, scalar
@@ -729,6 +739,7 @@ void k_stream(const StreamArgs a)
 // The price: two columns' rolling windows in registers (about 110 VGPRs, four waves per SIMD instead of five).
 // ---------------------------------------------------------------------------
 constexpr int HP_STRIP_W = 128;
+constexpr bool hp_fast_biased(int nt, bool lds_lut, int prec) { return prec == 1 && !lds_lut && nt == 1024; }
 
 struct HpRow { float va, vb, p1a, p1b, p2a, p2b; };
 
@@ -799,21 +810,23 @@ void k_hp(const StreamArgs a)
 {
     static_assert(MODE != MODE_DEMOSAIC, "the demosaic-only kernel is store-bound: k_stream");
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr uint32_t TAB_BYTES = TabsOf<PREC>::BYTES;
+    // the binary32 tables at their biased address where the workgroup has the CU's LDS to itself and no curve to stage
+    constexpr bool BIASED = hp_fast_biased(NT, LDS_LUT, PREC);
+    constexpr uint32_t TAB_AT = BIASED ? FAST_TABS_BIASED_AT : 0u, TAB_BYTES = TAB_AT + TabsOf<PREC>::BYTES;
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + TAB_BYTES);
     const int tid = threadIdx.x;
     constexpr uint32_t LDS_MP = TAB_BYTES + (LDS_LUT ? (uint32_t)RPF_CURVE_RESOLUTION * 2u : 0u);
     constexpr bool MULTI = mode_multi(MODE);
     assert_lds_base(smem);
-    stage16<NT, (int)(TAB_BYTES / 16)>(PREC ? reinterpret_cast<const uint4*>(a.ed.fast_tabs) : reinterpret_cast<const uint4*>(a.ed.tabs),
-                                       reinterpret_cast<uint4*>(smem), tid);
+    stage16<NT, (int)(TabsOf<PREC>::BYTES / 16)>(PREC ? reinterpret_cast<const uint4*>(a.ed.fast_tabs) : reinterpret_cast<const uint4*>(a.ed.tabs),
+                                                 reinterpret_cast<uint4*>(smem + TAB_AT), tid);
     if (LDS_LUT)
         stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright + (size_t)(MULTI ? a.ed.lds_bright_mask : 0u) * RPF_CURVE_RESOLUTION),
                                                    reinterpret_cast<uint4*>(lut), tid);
     if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();  // the only barrier of the kernel
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused, MULTI ? a.ed.lds_bright_mask : 0u};
-    const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC>(smem, a.ed.mp[0]);
+    const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC, true, BIASED>(smem, a.ed.mp[0]);
     const __amdgpu_buffer_rsrc_t band_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.cfa), 0, (int)((a.g.rows + 4u) * a.g.width * 2u), RPF_BUFFER_RSRC_FLAGS);
     // the tile's vignette falloff map: rows x W binary32 (run_hp checks that it exists and is shorter than 4 GiB)
@@ -1636,8 +1649,8 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
     const uint32_t total_pairs = (g.rows + bp + 1) / 2;
     a.strips = (g.width + (uint32_t)raw.xo + HP_STRIP_W - 1) / HP_STRIP_W;
     constexpr uint32_t WPB = NT / 64;
-    const size_t lds = TabsOf<PREC>::BYTES + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
-                       (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
+    const size_t lds = (hp_fast_biased(NT, LDS_LUT, PREC) ? FAST_TABS_BIASED_AT : 0u) + TabsOf<PREC>::BYTES +
+                       (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) + (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
     const bool vign = ed->vign_strength != 0.0f;
     if (PREC && !ed->fast_tabs) return hipErrorInvalidValue;
     // k_hp reads the vignette's falloff from the tile's map (the API layer builds it when the slider leaves 0)
