@@ -602,7 +602,7 @@ RPF_HD void edit_chain_fast(float (&r)[N], float (&g)[N], float (&b)[N], const u
         float out[3];
         for (int k = 0; k < 3; ++k) {
             const float c = lin[k];
-            const float hi = clamp01(__builtin_fmaf(chain_k_gamma_mul(T), powc_fast<POW_GAMMA>(c, T.gamma), -chain_k_gamma_off(T)));
+            const float hi = clamp01(srgb_upper_fast(c, T.gamma));  // 1.055 pow(c, 1 / 2.4) - 0.055 in one table evaluation
             const float lo = clamp01(c * chain_k_gamma_lin(T));
             out[k] = c <= RPF_F(0.0031308) ? lo : hi;
         }

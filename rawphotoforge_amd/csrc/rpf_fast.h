@@ -38,9 +38,9 @@ namespace rpf {
 // into the table: inputs below the first row read row 0, inputs above the last row its last entry.
 //   cube root   rows for e = -22 .. 0; row e = -22 is all zeros, so 0, subnormals and anything below 2^-21 return 0 (the
 //               chain's cube-root arguments are 0 or >= 7e-7 and <= 1.0000001, wgsl:65-67)
-//   gamma       rows for e = -9 .. 2; below 2^-9 the result is unspecified (finite): the chain takes the linear branch
-//               there (wgsl:99-102); at and above 8 the result is >= 1.9, which the chain's clamp turns into 1 like the
-//               exact value (wgsl:335)
+//   gamma       rows for e = -9 .. 2 (srgb_upper_fast below: the table carries the whole upper branch of linear_to_srgb);
+//               below 2^-9 the result is unspecified (finite): the chain takes the linear branch there (wgsl:99-102); at
+//               and above 8 the result is >= 1.9, which the chain's clamp turns into 1 like the exact value (wgsl:335)
 // ---------------------------------------------------------------------------
 struct FastPowEntry {
     float r, T, rho, pad;
@@ -112,7 +112,7 @@ __device__ __forceinline__ FastPowEntry fast_pow_read(const LdsFastPow& T, uint3
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f v = *(const __attribute__((address_space(3))) v4f*)(T.base + off);
-    return FastPowEntry{v.x, v.y, v.z, 0.0f};
+    return FastPowEntry{v.x, v.y, v.z, v.w};
 #else
     (void)T; (void)off;
     return FastPowEntry{0.0f, 0.0f, 0.0f, 0.0f};  // host pass of the HIP compilation: never called
@@ -137,6 +137,24 @@ RPF_HD float powc_fast(float x, const TabT& tab)
     p = __builtin_fmaf(t, p, K::c1);
     const float q = __builtin_fmaf(t, p, e.rho);
     return __builtin_fmaf(e.T, q, e.T);
+}
+
+// linear_to_srgb's upper branch, 1.055 pow(x, 1 / 2.4) - 0.055 (wgsl:98-100), as ONE evaluation of the gamma table: its
+// entries hold T = RN(1.055 V), pad = T2 = RN(W) and rho = RN((W - T2) / T) for W = 1.055 V - 0.055, so that the branch is
+// T2 + T q with the same q as a pow — one fma (which also carries the chain's clamp) instead of a pow's last fma and a
+// multiply-add.  One rounding for the whole branch: within 1 ulp of its true value on every binary32 of [2^-9, 8)
+// (tests/test_fast_math.py; the reference's three roundings — pow, times 1.055, minus 0.055 — stray up to 1.5 ulp from it).
+// The gamma table is therefore not a pow table: powc_fast is for the cube root.
+template <class TabT>
+RPF_HD float srgb_upper_fast(float x, const TabT& tab)
+{
+    using K = FastPowCoef<POW_GAMMA>;
+    const FastPowEntry e = fast_pow_read(tab, fast_pow_offset<POW_GAMMA>(x, tab));
+    const float t = __builtin_fmaf(x, e.r, -1.0f);
+    float p = __builtin_fmaf(t, fast_pow_c3<POW_GAMMA>(tab), K::c2);
+    p = __builtin_fmaf(t, p, K::c1);
+    const float q = __builtin_fmaf(t, p, e.rho);
+    return __builtin_fmaf(e.T, q, e.pad);
 }
 
 // ---------------------------------------------------------------------------
@@ -244,9 +262,12 @@ RPF_HD float hue_fraction_fast(float y, float x)
     };
     float f = fract(v);
     f = ay > ax ? fract(0.75f - f) : f;  // 16383.75 - v
-    f = x < 0.0f ? fract(0.5f - f) : f;  // 32767.5 - v
-    f = y < 0.0f ? fract(-f) : f;        // 65535 - v
-    return f;
+    // the two reflections about the axes in one: x < 0 maps f to frac(0.5 - f), y < 0 then to frac(-f); together
+    // frac(s f + c) with s = -1 when exactly one of x, y is negative and c = 0.5 when x is — sign bits and one addition
+    // (a zero of either sign lies ON the axis of its reflection, which leaves it where it is: -0 may count as negative)
+    const uint32_t sx = f2bits(x) & 0x80000000u, sy = f2bits(y) & 0x80000000u;
+    const float c = bits2f((uint32_t)((int32_t)f2bits(x) >> 31) & 0x3f000000u);  // 0.5f or 0
+    return fract(bits2f(f2bits(f) ^ sx ^ sy) + c);
 }
 
 // 2 * f32(pi) / 65535 as binary32: one index step in radians

@@ -99,6 +99,12 @@ static void build_fast_pow(FastPowEntry* tab, float cf)
             o.T = (float)V;
             o.rho = (float)((V - (long double)o.T) / (long double)o.T);
             o.pad = 0.0f;
+            if (KIND == POW_GAMMA) {  // the whole upper branch of linear_to_srgb (rpf_fast.h srgb_upper_fast): W = 1.055 V - 0.055
+                const long double G = (long double)(float)1.055, W = G * V - (long double)(float)0.055;
+                o.T = (float)(G * V);
+                o.pad = (float)W;
+                o.rho = (float)((W - (long double)o.pad) / (long double)o.T);
+            }
             if (KIND == POW_CBRT && row == 0) o.r = o.T = o.rho = 0.0f;  // everything below 2^-21 (and 0) -> 0
         }
     }

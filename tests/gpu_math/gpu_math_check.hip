@@ -226,13 +226,13 @@ extern "C" int gpu_fast_hue_fraction(const float* y, const float* x, uint64_t n,
     return rc;
 }
 
-// powc_fast (which: 0 = cube root, 1 = gamma) over the bit patterns [lo, lo + n) with the table the host built, and
+// powc_fast (which = 0: the cube root) / srgb_upper_fast (which = 1) over the bit patterns [lo, lo + n) with the table the host built, and
 // sincos_hue_fast for all 65536 indices: IEEE operations only, so these must be the host twin's bits
 __global__ void k_fast_pow_range(int which, uint32_t lo, uint64_t n, const rpf::FastTables* T, float* out)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const float x = rpf::bits2f(lo + (uint32_t)i);
-        out[i] = which == 0 ? rpf::powc_fast<rpf::POW_CBRT>(x, &T->cbrt[0]) : rpf::powc_fast<rpf::POW_GAMMA>(x, &T->gamma[0]);
+        out[i] = which == 0 ? rpf::powc_fast<rpf::POW_CBRT>(x, &T->cbrt[0]) : rpf::srgb_upper_fast(x, &T->gamma[0]);
     }
 }
 

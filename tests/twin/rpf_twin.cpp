@@ -157,14 +157,14 @@ void twin_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
 
 // ---- RPF_PRECISION_FAST builtins (rpf_fast.h) --------------------------------------------------
 float twin_fast_pow_cbrt(float x) { return rpf::powc_fast<rpf::POW_CBRT>(x, fast_tabs().cbrt); }
-float twin_fast_pow_gamma(float x) { return rpf::powc_fast<rpf::POW_GAMMA>(x, fast_tabs().gamma); }
+float twin_fast_srgb_upper(float x) { return rpf::srgb_upper_fast(x, fast_tabs().gamma); }
 void twin_fast_pow_range(int which, uint32_t bits_lo, uint32_t n, float* out)
 {
     const rpf::FastTables& T = fast_tabs();
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < (long long)n; ++i) {
         const float x = rpf::bits2f(bits_lo + (uint32_t)i);
-        out[i] = which == 0 ? rpf::powc_fast<rpf::POW_CBRT>(x, T.cbrt) : rpf::powc_fast<rpf::POW_GAMMA>(x, T.gamma);
+        out[i] = which == 0 ? rpf::powc_fast<rpf::POW_CBRT>(x, T.cbrt) : rpf::srgb_upper_fast(x, T.gamma);
     }
 }
 size_t twin_fast_tables(void* out, size_t cap)  // the FastTables as the product builds them (for the on-device checks)
