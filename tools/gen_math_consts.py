@@ -62,6 +62,38 @@ def hue_candidate_poly(nterms=5):
     return c32, float(np.abs(err).max())
 
 
+def fast_constants():
+    """rpf_fast.h: the eight-term hue-position polynomial (index units, divisor f32(2 pi)), the sine / cosine minimax
+    polynomials on [-pi/4, pi/4] and the three-term split of pi/2 (numpy + mpmath)."""
+    import numpy as np
+
+    def lawson(basis, target, weight, iters=300):
+        w = np.ones(len(target))
+        for _ in range(iters):
+            cc, *_ = np.linalg.lstsq(basis * (w * weight)[:, None], target * w * weight, rcond=None)
+            e = (basis @ cc - target) * weight
+            w = w * (1 + 3 * np.abs(e) / np.abs(e).max())
+            w /= w.mean()
+        return cc, np.abs(e).max()
+    n = 4000
+    z = (np.cos(np.pi * (np.arange(n) + 0.5) / n) + 1) / 2
+    q = np.sqrt(z)
+    c, _ = lawson(np.vander(z, 8, increasing=True) * q[:, None], np.arctan(q), np.ones(n))
+    k = 65535 / float(np.float32(2.0 * 3.14159265359))
+    print("// hue_position_fast / hue_fraction_fast:", ", ".join(f"{float(np.float32(v * k))!r}f" for v in c))
+    r = (np.cos(np.pi * (np.arange(n) + 0.5) / n) + 1) / 2 * 0.7954
+    r = r[r > 1e-4]
+    zz = r * r
+    S, es = lawson(np.vander(zz, 3, increasing=True), np.array([float((mp.sin(x) - x) / x ** 3) for x in map(mp.mpf, r)]), r ** 3 / np.sin(r))
+    Cc, ec = lawson(np.vander(zz, 3, increasing=True), np.array([float((mp.cos(x) - 1 + x * x / 2) / x ** 4) for x in map(mp.mpf, r)]), zz * zz / np.cos(r))
+    print("// sin:", [float(np.float32(v)) for v in S], "rel err", es, " cos:", [float(np.float32(v)) for v in Cc], "rel err", ec)
+    H = mp.mpf(1.5703125)
+    rest = mp.pi / 2 - H
+    e = mp.floor(mp.log(rest, 2))
+    M = mp.floor(rest / mp.mpf(2) ** (e - 10)) * mp.mpf(2) ** (e - 10)
+    print("// pi/2 =", float(H), "+", repr(float(M)), "+", repr(float(np.float32(float(rest - M)))), "; 2/pi =", float(np.float32(2 / np.pi)))
+
+
 def binomials(c_float32, kmax=5):
     """binomial(c, k), k = 1..kmax, for c a binary32 value, as binary64 hex literals (PowCoef in rpf_math.h)."""
     from fractions import Fraction
@@ -76,6 +108,7 @@ def binomials(c_float32, kmax=5):
 if __name__ == "__main__":
     import numpy as _np
     print("// hue_index candidate polynomial (index units), max error:", hue_candidate_poly())
+    fast_constants()
     for _name, _c in (("cbrt", _np.float32(1 / 3)), ("gamma", _np.float32(1 / 2.4)), ("decode", _np.float32(2.4))):
         print(f"// PowCoef {_name}:", binomials(_c))
     for deg in (7, 8, 9):
