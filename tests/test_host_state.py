@@ -145,3 +145,17 @@ def test_headless_editor_cannot_compute(ed):
         ed.apply_adjustments()
     with pytest.raises(R.GpuComputeError):
         ed.to_flat_vec_rgba()
+
+
+def test_precision_is_a_per_editor_hint():
+    """rpf_set_precision / rpf_get_precision on a headless editor (no device needed for the bookkeeping): exact by default,
+    unknown values refused, reset() leaves it alone (it is not edit state)."""
+    import rawphotoforge_amd as R
+    ed = R.PhotoEditor.headless(8, 8)
+    assert ed.precision == R.PRECISION_EXACT
+    ed.set_precision(R.PRECISION_FAST)
+    assert ed.precision == R.PRECISION_FAST
+    with pytest.raises(R.InvalidArgument):
+        ed.set_precision(7)
+    ed.reset()
+    assert ed.precision == R.PRECISION_FAST
