@@ -208,7 +208,11 @@ int rpf_set_shader_flavour(rpf_editor* e, int flavour);
  *   up to and including the brightness curve stays bit-identical to EXACT.  Measured against the oracle on uniformly random
  *   frames: median 1-2 ulp per channel, 92-98 % of the pixels within 1e-6 and 99.6 % within 1e-5; the rest sit where the hue
  *   index steps (the hue moves by one step of the index scale there, in the reference too: within 2e-3 for the default
- *   curves; a steep per-hue curve scales that) (tests/test_fast_math.py, tests/test_gpu_fast.py).  A hint: launches that
+ *   curves; a steep per-hue curve scales that) (tests/test_fast_math.py, tests/test_gpu_fast.py).  One caveat is the
+ *   reference's own: the hue of an ACHROMATIC pixel (grey, or clipped to white: a, b are rounding noise) is decided by that
+ *   noise.  Its chroma does not care, but a per-hue LIGHTNESS curve that varies with the hue then hands such a pixel the gain
+ *   of whatever index the noise picks — EXACT reproduces the oracle's pick bit for bit, FAST (like any backend whose pow
+ *   rounds differently) may pick another entry of that curve (tools/soak_parity.py documents and excludes the case).  A hint: launches that
  *   have no binary32 specialisation (packed input, the lens resample, the Godot-legacy flavour, user masks with an output
  *   layout other than RGBA32F or in the RGBA pass) compute the exact chain; a u16 Bayer band (with or without user masks)
  *   and the RGBA pass with only "main" have one.  Not versioned edit
