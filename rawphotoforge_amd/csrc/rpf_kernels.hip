@@ -1845,6 +1845,17 @@ static hipError_t develop_packed_fmt(const LaunchCfg& cfg, const uint8_t* d_pack
 {
     const uint16_t* in = reinterpret_cast<const uint16_t*>(d_packed);
     const bool lut = needs_lds_lut(ed);
+    // RPF_PRECISION_FAST from packed rows (only "main", RGBA32F output; everything else computes the exact chain)
+    if (OUTFMT == OUT_RGBA_F32 && ed.precision == 1u && ed.fast_tabs && ed.num_masks == 1 && cfg.variant == 0) {
+        if (ed.mp[0].flags == MF_PRISTINE)
+            return run_stream<256, MODE_DEVELOP_1P, false, OUT_RGBA_F32, PK, 1>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+        if (ed.mp[0].flags & MF_HUE_IDENTITY)
+            return lut ? run_stream<1024, MODE_DEVELOP_1H, true, OUT_RGBA_F32, PK, 1>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
+                       : run_stream<256, MODE_DEVELOP_1H, false, OUT_RGBA_F32, PK, 1>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+        if (ed.hue_fused)
+            return lut ? run_stream<1024, MODE_DEVELOP_1, true, OUT_RGBA_F32, PK, 1>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk)
+                       : run_stream<256, MODE_DEVELOP_1, false, OUT_RGBA_F32, PK, 1>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);
+    }
     if (ed.num_masks == 1) {
         if (ed.mp[0].flags == MF_PRISTINE)
             return run_stream<256, MODE_DEVELOP_1P, false, OUTFMT, PK>(cfg, in, raw, g, &ed, d_out, s, 0, 0, pk);

@@ -247,8 +247,9 @@ def test_fast_develop_with_user_masks(gpu):
         _assert_fast_bounds(ed.rgba(), want, "masks", flip_bound=bound)
 
 
-def test_fast_falls_back_to_the_exact_chain_where_it_has_no_specialisation(gpu):
-    """Packed input has no binary32 specialisation — the launch computes the exact chain (bit-identical to the oracle)."""
+def test_fast_develop_from_packed_rows_and_its_fallback(gpu):
+    """12-bit packed rows (the unpack folded into the column-per-lane kernel): RGBA32F output has a binary32 specialisation —
+    bounds against the oracle; RGB-f32 output has none — the launch computes the exact chain, bit-identical to the oracle."""
     import torch
     h, w = 64, 96
     frame = util.bayer_uniform(h, w, seed=3) & 0x0FFF
@@ -257,14 +258,21 @@ def test_fast_falls_back_to_the_exact_chain_where_it_has_no_specialisation(gpu):
     pad[2:h + 2] = frame
     packed = O.pack_bayer(pad, 12, order=O.PACK_LSB_FIRST)
     pb = torch.from_numpy(np.ascontiguousarray(packed)).cuda()
-    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
-    ed.set_precision(R.PRECISION_FAST)
-    ed.dev_develop_packed(pb.data_ptr(), packed.shape[1], 12, util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32,
-                          torch.cuda.current_stream().cuda_stream, R.PACK_LSB_FIRST)
-    torch.cuda.synchronize()
-    want = O.develop(frame, rp, [util.params_D()])
-    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    stream = torch.cuda.current_stream().cuda_stream
+    for pname in ("D", "S"):
+        spec = dict(syn.PARAM_SETS[pname], vignette=0)
+        want = O.develop(frame, rp, [util.oracle_params(spec)])
+        ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+        syn.configure(ed, spec)
+        ed.set_precision(R.PRECISION_FAST)
+        out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        ed.dev_develop_packed(pb.data_ptr(), packed.shape[1], 12, util.to_raw(rp), out.data_ptr(), R.OUT_RGBA_F32, stream, R.PACK_LSB_FIRST)
+        torch.cuda.synchronize()
+        _assert_fast_bounds(out.cpu().numpy(), want, ("packed", pname))
+        rgb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        ed.dev_develop_packed(pb.data_ptr(), packed.shape[1], 12, util.to_raw(rp), rgb.data_ptr(), R.OUT_RGB_F32, stream, R.PACK_LSB_FIRST)
+        torch.cuda.synchronize()
+        assert np.array_equal(rgb.cpu().numpy().view(np.uint32), np.ascontiguousarray(want[..., :3]).view(np.uint32))
 
 
 def test_fast_develop_full_frame_statistics(gpu):
