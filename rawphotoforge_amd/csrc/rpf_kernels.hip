@@ -1,10 +1,14 @@
 // rpf_kernels.hip — hand-written gfx950 (CDNA4) kernels of the RAW development hot path.
 //
 //   k_stream<MODE_DEMOSAIC>   u16 Bayer -> linear RGBA32F          (BASELINE config 2)
-//   k_stream<MODE_DEVELOP>    u16 Bayer -> display RGBA32F, fused  (BASELINE config 3: demosaic + WB +
-//                              camera matrix + the whole of wgsl main in ONE pass: 2 B in, 16 B out per pixel)
+//   k_hp<MODE_DEVELOP...>     u16 Bayer -> display RGBA32F, fused  (BASELINE config 3: demosaic + WB + camera matrix + the
+//                              whole of wgsl main in ONE pass: 2 B in, 16 B out per pixel) — the horizontal-pair kernel,
+//                              shipped since round 3 for launches with only "main"
+//   k_stream<MODE_DEVELOP...> the same chain, column-per-lane front end: packed input, launches with user masks
 //   k_tile<...>               the same two, LDS-tile front end (variant 1; the first design, kept for A/B)
 //   k_apply                   RGBA32F -> RGBA32F, wgsl main only   (what the reference's wgpu pass does)
+//   k_hp / k_stream / k_apply <..., PREC = 1>: the RPF_PRECISION_FAST specialisations (binary32-only builtins, rpf_fast.h;
+//                              the default, PREC = 0, evaluates every builtin correctly rounded and is the parity gate)
 //
 // Replaces rust/photo-editor/src/wgpu_shader.wgsl:265-337 (kernel) and the dispatch half of
 // rust/photo-editor/src/gpu_image_processing.rs:214-400.  Not a translation of the WGSL
