@@ -589,6 +589,10 @@ def main():
                 "max_abs_difference": round(float(dd.max()), 7)}
             sec["fast_precision"] = fe
             del dev_f, out_exact, dd, ulp
+            dev_fs = make_developer(configure_with(syn.PARAM_SETS["S"], "fast"))   # ... and under the edits a user's session dispatches
+            sec["fast_precision_edit_set_S"] = entry(*timed(lambda: dev_fs.step(band, out, out_fmt, out_bpp, False), nsec),
+                                                     "RPF_PRECISION_FAST, edit set S (run-time flags, brightness curve in LDS, vignette map, all tone sliders)")
+            del dev_fs
         npool = 8
         frames = [band] + [tiles.make_band_buffer(gen(rows, W, seed=20260700 + i), device="cuda") for i in range(1, npool)]
         k = [0]
