@@ -214,8 +214,8 @@ int rpf_set_shader_flavour(rpf_editor* e, int flavour);
  *   of whatever index the noise picks — EXACT reproduces the oracle's pick bit for bit, FAST (like any backend whose pow
  *   rounds differently) may pick another entry of that curve (tools/soak_parity.py documents and excludes the case).  A hint: launches that
  *   have no binary32 specialisation (the lens resample, the Godot-legacy flavour, user masks or packed input with an output
- *   layout other than RGBA32F, user masks over packed input or in the RGBA pass) compute the exact chain; a u16 Bayer band
- *   with or without user masks, a packed band with only "main" and the RGBA pass with only "main" have one.  Not versioned edit
+ *   layout other than RGBA32F, user masks over packed input) compute the exact chain; a u16 Bayer band and the RGBA pass,
+ *   each with or without user masks, and a packed band with only "main" have one.  Not versioned edit
  *   state: takes effect at the next apply / rpf_dev_* call.  No reference counterpart (wgpu has one precision, the driver's). */
 enum { RPF_PRECISION_EXACT = 0, RPF_PRECISION_FAST = 1 };
 int rpf_set_precision(rpf_editor* e, int precision);

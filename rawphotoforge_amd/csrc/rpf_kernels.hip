@@ -1094,6 +1094,7 @@ struct TexFetch {
 // SINGLE: 0 = any number of masks, 1 = only "main", 2 = only "main" with an identity hue curve (HUE_DIRECT),
 // 3 = only a pristine "main" (MF_PRISTINE known at compile time; sincos_hue as in 1)
 //         5 (PREC = 1 only) = only "main", without a hue curve: the rotation form of edit_chain_fast
+//         6 (PREC = 1 only) = user masks, no mask with a hue curve: the rotation form over all masks (0 with PREC = 1: the builtin route)
 // PREC: 0 = exact (rpf_math.h), 1 = RPF_PRECISION_FAST (rpf_fast.h; SINGLE 3, 5 or 1, no lens resample, active flavour)
 template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE, int PREC = 0>
 __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
                                        reinterpret_cast<uint4*>(smem), tid);
     if (LDS_LUT)
         stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright), reinterpret_cast<uint4*>(lut), tid);
-    if (SINGLE == 0) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
+    if (SINGLE == 0 || SINGLE == 6) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
     const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC>(smem, a.ed.mp[0]);
@@ -1210,11 +1211,13 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
                 r[k] *= gain; g[k] *= gain; b[k] *= gain;
             }
         }
-        if (!SINGLE && a.ed.num_masks > 1)
+        if ((SINGLE == 0 || SINGLE == 6) && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
         if constexpr (PREC == 1) {
             if (SINGLE == 3) edit_chain_fast<2, (int)MF_PRISTINE, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
             else if (SINGLE == 5) edit_chain_fast<2, -1, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+            else if (SINGLE == 6) edit_chain_fast<2, -1, true>(r, g, b, active, LdsMaskParams{a.ed.mp, LDS_MP}, a.ed.num_masks, luts, tabs);
+            else if (SINGLE == 0) edit_chain_fast<2>(r, g, b, active, LdsMaskParams{a.ed.mp, LDS_MP}, a.ed.num_masks, luts, tabs);
             else edit_chain_fast<2, -1, false, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);  // a hue curve: the fused hue table
         } else if (SINGLE == 3)
             edit_chain<2, 0, (int)MF_PRISTINE>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
@@ -1940,7 +1943,7 @@ static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
 {
     constexpr int NT = LDS_LUT ? 1024 : 256;
     const size_t lds = TabsOf<PREC>::BYTES + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
-                       (SINGLE == 0 ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
+                       (SINGLE == 0 || SINGLE == 6 ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
     auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT, SINGLE, PREC>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
@@ -1973,6 +1976,12 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
             return lut ? run_apply<true, false, OUTFMT, 5, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 5, 1>(cfg, a, s);
         if (!a.ed.hue_fused) return hipErrorInvalidValue;  // a hue curve without its table: the API layer builds it
         return lut ? run_apply<true, false, OUTFMT, 1, 1>(cfg, a, s) : run_apply<false, false, OUTFMT, 1, 1>(cfg, a, s);
+    }
+    // ... and with user masks (RGBA32F output): the rotation form when no mask has a hue curve, else the builtin route
+    if (OUTFMT == OUT_RGBA_F32 && a.ed.precision == 1u && a.ed.fast_tabs && a.ed.num_masks > 1 && !lens && a.ed.flags == 0 && cfg.variant == 0) {
+        if (all_hue_identity(a.ed))
+            return lut ? run_apply<true, false, OUT_RGBA_F32, 6, 1>(cfg, a, s) : run_apply<false, false, OUT_RGBA_F32, 6, 1>(cfg, a, s);
+        return lut ? run_apply<true, false, OUT_RGBA_F32, 0, 1>(cfg, a, s) : run_apply<false, false, OUT_RGBA_F32, 0, 1>(cfg, a, s);
     }
     if (a.ed.num_masks == 1) {  // "main" only (the common case): per-mask loops and mask-plane reads compiled out
         // (HUE_DIRECT, SINGLE == 2, is not used here: with this kernel's 16-B/px input stream the 32-byte table read

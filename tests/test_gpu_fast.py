@@ -197,6 +197,35 @@ def test_fast_rgba_pass_against_the_oracle(gpu, pname):
     assert np.array_equal(np.asarray(ed.rgba(), np.float32).view(np.uint32), want.view(np.uint32))
 
 
+def test_fast_rgba_pass_with_user_masks(gpu):
+    """The RGBA pass with user masks in the fast precision (the rotation form over all masks, or the builtin route when a
+    mask has a hue curve): an editor created from linear RGB, two user masks."""
+    rng = np.random.default_rng(41)
+    h, w = 96, 260
+    rgb = rng.random((h, w, 3), dtype=np.float32)
+    m1 = np.zeros((h, w), np.float32)
+    m1[:, 100:] = 1.0
+    m2 = np.zeros((h, w), np.float32)
+    m2[10:80, 20:200] = 1.0
+    ps = util.params_S()
+    ps.vignette = 0
+    masks = np.stack([np.ones((h, w), np.float32), O.binarize_mask(m1), O.binarize_mask(m2)])
+    img = np.concatenate([rgb, np.ones((h, w, 1), np.float32)], 2)
+    # (set G's lightness curve varies with the hue: a pixel whose chroma is rounding noise gets the gain of whatever index
+    # the noise picks — include/rpf.h's caveat — hence the wide bound on the few pixels beyond 1e-5 there)
+    for main, second, bound in ((util.params_D(), ps, 4e-3), (util.oracle_params(syn.PARAM_SETS["T"]), util.params_G(), 1e-1)):
+        ed = R.PhotoEditor.new_from_rgb_f32(gpu, rgb.reshape(-1), h, w)
+        ed.add_mask("right", m1)
+        ed.add_mask("box", m2)
+        util.configure_editor(ed, main)
+        util.configure_editor(ed, ps, mask_name="right", main=False)
+        util.configure_editor(ed, second, mask_name="box", main=False)
+        ed.set_precision(R.PRECISION_FAST)
+        ed.apply_adjustments()
+        want = O.apply(img, [main, ps, second], masks=masks)
+        _assert_fast_bounds(ed.rgba(), want, "apply masks", flip_bound=bound)
+
+
 def test_fast_develop_on_row_bands(gpu):
     """Row bands of a frame (odd first rows, every CFA phase) through the device-pointer layer in the fast precision: the
     vignette's falloff map and the rotation form use the band's GLOBAL position; bounds against the oracle's rows."""
