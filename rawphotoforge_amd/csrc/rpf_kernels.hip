@@ -1107,11 +1107,13 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
     assert_lds_base(smem);
     stage16<NT, (int)(TAB_BYTES / 16)>(PREC ? reinterpret_cast<const uint4*>(a.ed.fast_tabs) : reinterpret_cast<const uint4*>(a.ed.tabs),
                                        reinterpret_cast<uint4*>(smem), tid);
-    if (LDS_LUT)
-        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright), reinterpret_cast<uint4*>(lut), tid);
-    if (SINGLE == 0 || SINGLE == 6) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
+    constexpr bool MULTI = SINGLE == 0 || SINGLE == 6;
+    if (LDS_LUT)  // "main"'s curve, or — launches with user masks whose "main" has none — a user mask's (DeviceEdit::lds_bright_mask)
+        stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright + (size_t)(MULTI ? a.ed.lds_bright_mask : 0u) * RPF_CURVE_RESOLUTION),
+                                                   reinterpret_cast<uint4*>(lut), tid);
+    if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
     __syncthreads();
-    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused};
+    DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused, MULTI ? a.ed.lds_bright_mask : 0u};
     const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC>(smem, a.ed.mp[0]);
     const int W = (int)a.g.width, H = (int)a.g.height;
     const uint32_t npix = a.g.rows * a.g.width;  // <= 2^31 (check_geom)
@@ -1964,9 +1966,15 @@ static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
 }
 
 template <int OUTFMT>
-static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
+static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a0, hipStream_t s)
 {
-    const bool lut = needs_lds_lut(a.ed);
+    // launches with user masks whose "main" has no brightness curve stage the first user mask's that has one (up to 8 masks;
+    // variants 10 and 23, A/B: off) — as the fused develop launches do (develop_fmt)
+    ApplyArgs a = a0;
+    bool lut = needs_lds_lut(a.ed);
+    if (!lut && a.ed.num_masks > 1 && a.ed.num_masks <= 8 && cfg.variant != 10 && cfg.variant != 23)
+        for (uint32_t m = 1; m < a.ed.num_masks && !lut; ++m)
+            if (!(a.ed.mp[m].flags & MF_BRIGHT_IDENTITY)) { a.ed.lds_bright_mask = m; lut = true; }
     const bool lens = a.ed.lens_strength != 0.0f;
     // RPF_PRECISION_FAST: the reference's own pass with the binary32-only chain (rpf_fast.h) — "main" alone, no lens
     // resample, the active shader flavour; every other launch computes the exact chain
