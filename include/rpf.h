@@ -59,7 +59,12 @@ extern "C" {
 #endif
 
 #define RPF_CURVE_RESOLUTION 65536 /* lib.rs:17 */
-#define RPF_MAX_MASKS 16           /* "main" + 15 user masks per editor */
+/* An editor holds any number of masks (lib.rs:481-499 has no limit).  Up to this many — "main" + 15 user masks — run the
+ * fused kernels from a Bayer frame: their coverage is ONE 16-bit word per pixel and their parameters travel with the launch.
+ * With more, rpf_apply_adjustments runs the demosaic-only kernel and the RGBA pass (one 16-bit coverage plane per 16 masks,
+ * parameters in device memory; the same bits), and the fused tile / band entry points (rpf_dev_develop*, rpf_shard_develop*)
+ * return RPF_ERR_INVALID_ARGUMENT: rpf_dev_demosaic + rpf_dev_apply are the two launches there. */
+#define RPF_FUSED_MASKS 16
 
 typedef enum rpf_status {
     RPF_OK = 0,
@@ -80,8 +85,7 @@ typedef enum rpf_status {
     RPF_ERR_INTERP_MISSING_CONTROL_POINTS = 21,
     RPF_ERR_INTERP_EMPTY_CONTROL_POINTS = 22,
     /* this ABI's own */
-    RPF_ERR_INVALID_ARGUMENT = 32,
-    RPF_ERR_TOO_MANY_MASKS = 33
+    RPF_ERR_INVALID_ARGUMENT = 32
 } rpf_status;
 
 typedef struct rpf_processor rpf_processor;
@@ -175,7 +179,7 @@ int rpf_set_oklch_saturation_curve(rpf_editor* e, const int32_t* curve, size_t c
 int rpf_set_oklch_lightness_curve(rpf_editor* e, const int32_t* curve, size_t curve_len, const int32_t* xs,
                                   size_t n_x, const int32_t* ys, size_t n_y, const char* mask_name);
 
-/* mask: height*width f32, binarised v >= main.mask_range ? 1 : 0 (lib.rs:481-487) */
+/* mask: height*width f32, binarised v >= main.mask_range ? 1 : 0 (lib.rs:481-487).  No limit on their number (RPF_FUSED_MASKS). */
 int rpf_add_mask(rpf_editor* e, const char* name, const float* mask);
 int rpf_remove_mask(rpf_editor* e, const char* name); /* "main" is kept (lib.rs:501-505) */
 int rpf_set_mask_range(rpf_editor* e, float mask_range); /* EditParameters.mask_range is a pub field */
@@ -373,7 +377,9 @@ int rpf_shard_timing(rpf_shard* s, uint32_t* launches, double* total_ms);
  * 8 = no splitting of the last, incomplete round of work items, 9 = 8-row instead of 32-/16-row work items,
  * 10 = brightness curve gathered from L2 instead of staged in LDS, 11 = cos / sin of the hue evaluated (sincos_hue)
  * also when the hue curve is the identity (instead of read with the hue-index table entry);
- * demosaic: 1 = LDS-tile front end, 3 = ordinary (not nontemporal) stores, 4 = 16-row items.  Same output bits. */
+ * demosaic: 1 = LDS-tile front end, 3 = ordinary (not nontemporal) stores, 4 = 16-row items;
+ * RGBA pass with more than RPF_FUSED_MASKS masks: 24 = the masks' parameters read from device memory instead of staged in
+ * LDS (what editors with more than 1024 masks run).  Same output bits. */
 int rpf_set_kernel_variant(rpf_processor* p, int variant);
 
 #ifdef __cplusplus

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPF_HIP_LIB") or os.path.join(_HERE, "librpf_hip.so")
 
 CURVE_RESOLUTION = 65536
-MAX_MASKS = 16
+FUSED_MASKS = 16  # RPF_FUSED_MASKS: "main" + 15 user masks run the fused kernels; an editor may hold more
 
 # rpf_status
 OK = 0
@@ -29,7 +29,6 @@ ERR_INTERP_INVALID_CURVE_LENGTH = 20
 ERR_INTERP_MISSING_CONTROL_POINTS = 21
 ERR_INTERP_EMPTY_CONTROL_POINTS = 22
 ERR_INVALID_ARGUMENT = 32
-ERR_TOO_MANY_MASKS = 33
 
 OUT_RGBA_F32, OUT_RGB_F32, OUT_RGB_U8 = 0, 1, 2
 CFA_RGGB, CFA_BGGR, CFA_GRBG, CFA_GBRG = 0, 1, 2, 3

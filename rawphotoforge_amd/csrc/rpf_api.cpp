@@ -178,14 +178,16 @@ static int sync_edit_state_impl(rpf_editor* e)
     // gpu_image_processing.rs:257-307, and its callers re-send all four curves every frame, web/main.ts:809-826)
     std::vector<uint16_t> bright;
     std::vector<ushort4> hsl;
+    std::vector<MaskParams> all_mp(n);
     for (uint32_t m = 0; m < n; ++m) {
         const EditParameters& p = e->state.masks[m].params;
-        e->dev.mp[m] = make_mask_params(p);
+        all_mp[m] = make_mask_params(p);
+        if (m < RPF_MASKS_PER_WORD) e->dev.mp[m] = all_mp[m];
         CurveStamps& up = e->uploaded_curves[m];
         // an identity brightness curve / trivial hue-saturation-lightness curves are never read by the kernels
         // (make_mask_params flags them): nothing to pack or upload for them
-        const bool bright_read = !(e->dev.mp[m].flags & MF_BRIGHT_IDENTITY);
-        const bool hsl_read = (e->dev.mp[m].flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) !=
+        const bool bright_read = !(all_mp[m].flags & MF_BRIGHT_IDENTITY);
+        const bool hsl_read = (all_mp[m].flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) !=
                               (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
         if (bright_read && up.v[RPF_CURVE_BRIGHTNESS] != p.curve_ver[RPF_CURVE_BRIGHTNESS]) {
             bright.resize(RPF_CURVE_RESOLUTION);
@@ -211,6 +213,19 @@ static int sync_edit_state_impl(rpf_editor* e)
             for (int c = RPF_CURVE_HUE; c <= RPF_CURVE_LIGHTNESS; ++c) up.v[c] = p.curve_ver[c];
         }
     }
+    // More masks than the kernel-argument segment holds parameters for (the reference has no limit, lib.rs:481-499): all
+    // of them in device memory, read by the RGBA pass's general kernel (rpf_launch.h DeviceEdit::mp_wide).
+    if (n > RPF_MASKS_PER_WORD) {
+        if ((rc = quiesce())) return rc;
+        if (e->mp_wide_capacity < n) {
+            if (e->d_mp_wide) HIP_TRY(hipFree(e->d_mp_wide));
+            e->d_mp_wide = nullptr; e->mp_wide_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&e->d_mp_wide, (size_t)n * sizeof(MaskParams)));
+            e->mp_wide_capacity = n;
+        }
+        HIP_TRY(hipMemcpy(e->d_mp_wide, all_mp.data(), (size_t)n * sizeof(MaskParams), hipMemcpyHostToDevice));
+    }
+    e->dev.mp_wide = n > RPF_MASKS_PER_WORD ? e->d_mp_wide : nullptr;
     // One mask whose hue / saturation / lightness curves are not all trivial: fold them into the editor's fused hue table
     // (one gather per pixel instead of two and sincos_hue); rebuilt only when what it is made of changed.
     {
@@ -262,15 +277,27 @@ static int sync_edit_state_impl(rpf_editor* e)
             HIP_TRY(hipMalloc((void**)&e->d_masks, plane * planes));
             e->mask_capacity = planes;
         }
-        if (planes && !e->d_mask_bits) HIP_TRY(hipMalloc((void**)&e->d_mask_bits, plane * sizeof(uint16_t)));
+        // one u16 of coverage bits per pixel and 16 masks: plane 0 = user masks 1..15 (bit j: mask j + 1), plane g >= 1 =
+        // masks 16 g .. 16 g + 15 (rpf_chain.h WideMasks)
+        const uint32_t bit_planes = planes ? (n + RPF_MASKS_PER_WORD - 1) / RPF_MASKS_PER_WORD : 0;
         if (planes && (rc = quiesce())) return rc;
+        if (bit_planes > e->mask_bit_planes) {
+            if (e->d_mask_bits) HIP_TRY(hipFree(e->d_mask_bits));
+            e->d_mask_bits = nullptr; e->mask_bit_planes = 0;
+            HIP_TRY(hipMalloc((void**)&e->d_mask_bits, plane * sizeof(uint16_t) * bit_planes));
+            e->mask_bit_planes = bit_planes;
+        }
         for (uint32_t m = 1; m < n; ++m)
             HIP_TRY(hipMemcpy(e->d_masks + (size_t)(m - 1) * plane, e->state.masks[m].binary.data(), plane,
                               hipMemcpyHostToDevice));
-        if (planes) {  // (after quiesce(): nothing is in flight; the editor's stream orders it before the next apply)
-            HIP_TRY(launch_combine_masks(e->d_masks, planes, plane, e->d_mask_bits, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));  // rpf_dev_* callers launch on their own streams
+        // (after quiesce(): nothing is in flight; the editor's stream orders it before the next apply)
+        for (uint32_t gp = 0; gp < bit_planes; ++gp) {
+            const uint32_t first = gp ? gp * RPF_MASKS_PER_WORD : 1u;  // first mask of the plane
+            const uint32_t last = (gp + 1) * RPF_MASKS_PER_WORD < n ? (gp + 1) * RPF_MASKS_PER_WORD : n;
+            HIP_TRY(launch_combine_masks(e->d_masks + (size_t)(first - 1) * plane, last - first, plane,
+                                         e->d_mask_bits + (size_t)gp * plane, e->stream));
         }
+        if (planes) HIP_TRY(hipStreamSynchronize(e->stream));  // rpf_dev_* callers launch on their own streams
         e->dev.mask_bits = planes ? e->d_mask_bits : nullptr;
         e->uploaded_masks = e->state.masks_version;
     }
@@ -437,7 +464,7 @@ void rpf_editor_destroy(rpf_editor* e)
         // than freed under a thread that will still touch it; the caller has been told (rpf_shard_flush / _drain failed).
         if (api_editor_quiesce(e) != RPF_OK) return;
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits,
+        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits, e->d_mp_wide,
                         e->d_vign_falloff, e->d_hue_fused_alloc};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
@@ -794,10 +821,12 @@ int rpf_apply_adjustments(rpf_editor* e)
     // crate stores them (rust-godot-legacy/photo-editor/src/image.rs) — srgb_to_linear on the sampled input.
     // A Bayer editor's frame is linear already (the legacy crate let rawler encode it, then decoded it here).
     e->dev.flags = flavour_flags(e);
-    if (e->is_bayer && e->dev.lens_strength == 0.0f && e->dev.flags == 0) {
+    if (e->is_bayer && e->dev.lens_strength == 0.0f && e->dev.flags == 0 && e->dev.num_masks <= RPF_MASKS_PER_WORD) {
         HIP_TRY(launch_develop(cfg, e->d_cfa, e->raw, e->geom, e->dev, e->d_image, OUT_RGBA_F32, e->stream));
     } else {
-        if (e->is_bayer && (rc = ensure_linear(e))) return rc;  // resampling needs the demosaiced frame
+        // resampling needs the demosaiced frame; more than 16 masks run the RGBA pass's general kernel (same bits: the
+        // fused kernel is the demosaic-only kernel's arithmetic followed by the pass's)
+        if (e->is_bayer && (rc = ensure_linear(e))) return rc;
         HIP_TRY(launch_apply(cfg, e->d_original, e->geom, e->dev, e->d_image, OUT_RGBA_F32, e->stream));
     }
     e->image_valid = true;
@@ -943,6 +972,9 @@ int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* 
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only: use rpf_dev_demosaic, "
                                               "then rpf_dev_apply, for the Godot-legacy flavour");
+    if (e->dev.num_masks > RPF_MASKS_PER_WORD)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel takes \"main\" + 15 user masks: with more, rpf_dev_demosaic into a "
+                                              "buffer of yours, then rpf_dev_apply (the same bits)");
     if ((hipStream_t)stream != e->stream) e->foreign_streams = true;
     e->dev.flags = 0;
     HIP_TRY(launch_develop(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->dev, d_out, out_format,
@@ -976,6 +1008,9 @@ int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_st
                     "lens distortion resamples the whole frame: unpack + demosaic first, then rpf_dev_apply on the full frame");
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
+    if (e->dev.num_masks > RPF_MASKS_PER_WORD)
+        return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel takes \"main\" + 15 user masks: with more, rpf_dev_unpack_bayer and "
+                                              "rpf_dev_demosaic into buffers of yours, then rpf_dev_apply (the same bits)");
     if ((hipStream_t)stream != e->stream) e->foreign_streams = true;
     e->dev.flags = 0;
     HIP_TRY(launch_develop_packed(cfg_of(e->proc), d_packed, (uint32_t)row_stride, bits, order, make_raw_params(*raw), e->geom,

@@ -9,7 +9,10 @@
 
 namespace rpf {
 
-#define RPF_MAX_MASKS 16
+// Masks whose coverage travels in ONE word per pixel ("main" + 15 user masks: DeviceEdit::mask_bits) and whose parameters
+// travel in the kernel-argument segment.  An editor may hold more (the reference has no limit, lib.rs:481-499): their
+// coverage lies in further 16-bit planes, 16 masks each (WideMasks below).
+#define RPF_MASKS_PER_WORD 16
 #define RPF_CURVE_RESOLUTION 65536  // lib.rs:17
 
 enum MaskFlags : uint32_t {
@@ -345,10 +348,43 @@ RPF_HD HueFused hue_fused_entry(const HueBound& hb, uint32_t hue_v, uint32_t sat
     return e;
 }
 
+// Masks beyond the first RPF_MASKS_PER_WORD (edit_chain's `wide` argument).  Mask m >= 16 is bit m % 16 of plane m / 16,
+// planes `stride` elements apart (plane 0 is the first word's: bit j = user mask j + 1); their parameters and curves are
+// slot m of the same arrays as everybody's (Params, Luts).  NoWideMasks: the editor has none — nothing is instantiated.
+struct NoWideMasks {
+    static constexpr bool enabled = false;
+};
+template <int N>
+struct WideMasks {
+    static constexpr bool enabled = true;
+    uint32_t total;           // masks of the editor, "main" included (> RPF_MASKS_PER_WORD)
+    const uint16_t* planes;
+    size_t stride;
+    size_t pix[N];            // the N pixels' index into a plane
+    RPF_HD uint32_t word(int n, uint32_t plane) const { return planes[(size_t)plane * stride + pix[n]]; }
+};
+
+// The coverage words of plane `plane` at the N pixels, and (returned) which of its masks cover a pixel of this wavefront.
+template <int N, class Wide>
+RPF_HD uint32_t wide_plane_words(const Wide& wide, uint32_t plane, uint32_t (&w)[N])
+{
+    uint32_t any = 0;
+    for (int n = 0; n < N; ++n) { w[n] = wide.word(n, plane); any |= w[n]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t u = 0;
+    for (uint32_t j = 0; j < RPF_MASKS_PER_WORD; ++j)
+        u |= (__builtin_amdgcn_ballot_w64((any >> j) & 1u) != 0ull) ? (1u << j) : 0u;
+    any = u;
+#endif
+    const uint32_t left = wide.total - plane * RPF_MASKS_PER_WORD;  // masks the plane holds, if it is the last
+    return left < RPF_MASKS_PER_WORD ? any & ((1u << left) - 1u) : any;
+}
+
 // STATIC_FLAGS (>= 0): "main"'s flag word, known at compile time (the caller's promise that mp[0].flags equals it).
-template <int N, int HUE_MODE = 0, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs>
+// num_masks: the masks of the first word (<= RPF_MASKS_PER_WORD); `wide`: the others (WideMasks), in mask order after them.
+template <int N, int HUE_MODE = 0, int STATIC_FLAGS = -1, class Params, class Luts, class Tabs, class Wide = NoWideMasks>
 RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32_t (&active)[N],
-                       const Params& mp, uint32_t num_masks, const Luts& luts, const Tabs& T)
+                       const Params& mp, uint32_t num_masks, const Luts& luts, const Tabs& T, const Wide& wide = Wide())
 {
     const float inv65535 = (float)(1.0 / 65535.0);
     mask_rgb_stage<N, STATIC_FLAGS>(mask_params_main(mp), 0u, luts, r, g, b, nullptr);  // "main" is all ones (lib.rs:193-196)
@@ -369,6 +405,21 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
         bool act[N];
         for (int n = 0; n < N; ++n) act[n] = (active[n] >> m) & 1u;
         mask_rgb_stage<N>(mask_params_user(mp, m), m, luts, r, g, b, act);
+    }
+    // the masks of the further planes, a plane at a time
+    if constexpr (Wide::enabled) {
+        static_assert(HUE_MODE == 0, "more than one mask: the general hue path");
+        for (uint32_t plane = 1; plane * RPF_MASKS_PER_WORD < wide.total; ++plane) {
+            uint32_t w[N];
+            const uint32_t any = wide_plane_words(wide, plane, w);
+            for (uint32_t j = 0; j < RPF_MASKS_PER_WORD; ++j) {
+                if (!((any >> j) & 1u)) continue;
+                const uint32_t m = plane * RPF_MASKS_PER_WORD + j;
+                bool act[N];
+                for (int n = 0; n < N; ++n) act[n] = (w[n] >> j) & 1u;
+                mask_rgb_stage<N>(mask_params_user(mp, m), m, luts, r, g, b, act);
+            }
+        }
     }
 
     // linear_srgb_to_oklch, wgsl:64-75.  The hue is only ever used as a curve index (hue_index, rpf_math.h).
@@ -431,6 +482,30 @@ RPF_HD void edit_chain(float (&r)[N], float (&g)[N], float (&b)[N], const uint32
     }
     for (uint32_t m = 1; m < num_masks; ++m)
         if ((any_active >> m) & 1u) oklch_stage(m, false);
+    if constexpr (Wide::enabled) {  // oklch_stage for the masks of the further planes
+        for (uint32_t plane = 1; plane * RPF_MASKS_PER_WORD < wide.total; ++plane) {
+            uint32_t w[N];
+            const uint32_t any = wide_plane_words(wide, plane, w);
+            for (uint32_t j = 0; j < RPF_MASKS_PER_WORD; ++j) {
+                if (!((any >> j) & 1u)) continue;
+                const uint32_t m = plane * RPF_MASKS_PER_WORD + j;
+                const MaskParams P = mask_params_user(mp, m);
+                const bool trivial = (P.flags & (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST)) ==
+                                     (MF_HUE_IDENTITY | MF_SAT_CONST | MF_LIGHT_CONST);
+                for (int n = 0; n < N; ++n) {
+                    const uint32_t hu = (uint32_t)(h[n] * 65535.0f);
+                    uint32_t nh = hu;
+                    float sat_gain = P.sat_gain, light_gain = P.light_gain;
+                    if (!trivial) luts.hsl(m, hu, P, nh, sat_gain, light_gain);
+                    const bool on = (bool)((w[n] >> j) & 1u);
+                    hue_k[n] = on ? nh : hue_k[n];
+                    h[n] = on ? div_u16_by(nh, 65535.0f, inv65535) : h[n];
+                    C[n] = on ? C[n] * sat_gain : C[n];
+                    L[n] = on ? L[n] * light_gain : L[n];
+                }
+            }
+        }
+    }
 
     // oklch_to_linear_srgb (wgsl:77-84), linear_to_srgb + clamp (wgsl:95-103, 335-336).  The hue reaching
     // here is always k/65535 for the integer k the last active mask fetched ("main" is always active).

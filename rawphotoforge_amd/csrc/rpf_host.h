@@ -370,9 +370,6 @@ struct EditState {
     Status add_mask(const char* name, const float* mask)
     {
         if (!name || !mask) return Status::err(RPF_ERR_INVALID_ARGUMENT, "add_mask: null argument");
-        if (masks.size() >= RPF_MAX_MASKS)
-            return Status::err(RPF_ERR_TOO_MANY_MASKS, "add_mask: at most " + std::to_string(RPF_MAX_MASKS) +
-                                                           " masks (including \"main\") per editor");
         const float mask_range = masks[0].params.mask_range;
         MaskState m;
         m.name = name;

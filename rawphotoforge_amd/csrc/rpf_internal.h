@@ -51,6 +51,10 @@ struct rpf_editor {
     ushort4* d_hsl = nullptr;
     uint8_t* d_masks = nullptr;       // user-mask planes as uploaded (u8, binarised)
     uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
+                                      // (more than 16 masks: one such plane per 16 masks, rpf_launch.h DeviceEdit::mask_bits)
+    uint32_t mask_bit_planes = 0;     // planes d_mask_bits holds room for
+    rpf::MaskParams* d_mp_wide = nullptr;  // every mask's parameters, for editors with more than 16 masks (DeviceEdit::mp_wide)
+    uint32_t mp_wide_capacity = 0;
     // one mask with non-trivial hue / saturation / lightness curves: the fused hue table and what it was built from
     void* d_hue_fused_alloc = nullptr;
     uint64_t hue_fused_stamp[3] = {~0ull, ~0ull, ~0ull};  // curve versions (hue, saturation, lightness) of "main"

@@ -160,7 +160,7 @@ __device__ __forceinline__ void stage_mask_params(const DeviceEdit& ed, unsigned
 {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(ed.mp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
-    for (int i = tid; i < (int)(sizeof(MaskParams) * RPF_MAX_MASKS / 4); i += nt) dst[i] = src[i];
+    for (int i = tid; i < (int)(sizeof(MaskParams) * RPF_MASKS_PER_WORD / 4); i += nt) dst[i] = src[i];
 }
 
 // The dynamic shared block must start at LDS address 0 for LdsTabs' constant addresses to be right (it does: these
@@ -1095,6 +1095,10 @@ struct TexFetch {
 // 3 = only a pristine "main" (MF_PRISTINE known at compile time; sincos_hue as in 1)
 //         5 (PREC = 1 only) = only "main", without a hue curve: the rotation form of edit_chain_fast
 //         6 (PREC = 1 only) = user masks, no mask with a hue curve: the rotation form over all masks (0 with PREC = 1: the builtin route)
+//         7 = more than RPF_MASKS_PER_WORD masks: the first 16 as in 0, then the further coverage planes, 16 masks each
+//             (rpf_chain.h WideMasks); every mask's parameters staged in LDS from DeviceEdit::mp_wide (48 B per mask: up to
+//             WIDE_LDS_MASKS of them)
+//         8 = the same with the parameters read from device memory (scalar loads per mask and step): any number of masks
 // PREC: 0 = exact (rpf_math.h), 1 = RPF_PRECISION_FAST (rpf_fast.h; SINGLE 3, 5 or 1, no lens resample, active flavour)
 template <int NT, bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE, int PREC = 0>
 __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
@@ -1112,6 +1116,11 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
         stage16<NT, RPF_CURVE_RESOLUTION * 2 / 16>(reinterpret_cast<const uint4*>(a.ed.bright + (size_t)(MULTI ? a.ed.lds_bright_mask : 0u) * RPF_CURVE_RESOLUTION),
                                                    reinterpret_cast<uint4*>(lut), tid);
     if (MULTI) stage_mask_params(a.ed, smem + LDS_MP, tid, NT);
+    if (SINGLE == 7) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.ed.mp_wide);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem + LDS_MP);
+        for (uint32_t i = tid; i < a.ed.num_masks * (uint32_t)(sizeof(MaskParams) / 4); i += NT) dst[i] = src[i];
+    }
     __syncthreads();
     DevLuts<LDS_LUT> luts{lut, a.ed.bright, a.ed.hsl, a.ed.hue_bounds, a.ed.hue_cs, a.ed.hue_fused, MULTI ? a.ed.lds_bright_mask : 0u};
     const typename TabsOf<PREC>::type tabs = make_lds_tabs<PREC>(smem, a.ed.mp[0]);
@@ -1213,7 +1222,7 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
                 r[k] *= gain; g[k] *= gain; b[k] *= gain;
             }
         }
-        if ((SINGLE == 0 || SINGLE == 6) && a.ed.num_masks > 1)
+        if ((SINGLE == 0 || SINGLE == 6 || SINGLE == 7 || SINGLE == 8) && a.ed.num_masks > 1)
             for (int k = 0; k < 2; ++k) active[k] = active_masks(a.ed, pix[k], npix);
         if constexpr (PREC == 1) {
             if (SINGLE == 3) edit_chain_fast<2, (int)MF_PRISTINE, true>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
@@ -1229,6 +1238,12 @@ __global__ __launch_bounds__(NT) void k_apply(const ApplyArgs a)
             edit_chain<2>(r, g, b, active, LdsMaskParams{a.ed.mp, LDS_MP}, a.ed.num_masks, luts, tabs);
         else if (SINGLE == 4)  // one mask with hue / saturation / lightness curves: through the editor's fused hue table
             edit_chain<2, 2>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
+        else if (SINGLE == 7)
+            edit_chain<2>(r, g, b, active, LdsMaskParams{a.ed.mp, LDS_MP}, (uint32_t)RPF_MASKS_PER_WORD, luts, tabs,
+                          WideMasks<2>{a.ed.num_masks, a.ed.mask_bits, (size_t)npix, {pix[0], pix[1]}});
+        else if (SINGLE == 8)
+            edit_chain<2>(r, g, b, active, a.ed.mp_wide, (uint32_t)RPF_MASKS_PER_WORD, luts, tabs,
+                          WideMasks<2>{a.ed.num_masks, a.ed.mask_bits, (size_t)npix, {pix[0], pix[1]}});
         else
             edit_chain<2>(r, g, b, active, a.ed.mp, 1u, luts, tabs);
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
@@ -1532,7 +1547,8 @@ static hipError_t check_geom(const TileGeom& g, bool bayer)
 
 static hipError_t check_edit(const DeviceEdit& ed)
 {
-    if (!ed.tabs || !ed.hue_bounds || !ed.hue_cs || !ed.bright || !ed.hsl || ed.num_masks < 1 || ed.num_masks > RPF_MAX_MASKS) return hipErrorInvalidValue;
+    if (!ed.tabs || !ed.hue_bounds || !ed.hue_cs || !ed.bright || !ed.hsl || ed.num_masks < 1) return hipErrorInvalidValue;
+    if (ed.num_masks > RPF_MASKS_PER_WORD && !ed.mp_wide) return hipErrorInvalidValue;
     if (ed.num_masks > 1 && !ed.mask_bits) return hipErrorInvalidValue;
     return hipSuccess;
 }
@@ -1573,7 +1589,7 @@ static hipError_t run_stream(const LaunchCfg& cfg, const uint16_t* d_cfa, const 
     constexpr uint32_t WPB = NT / 64;
     if (PREC && (!ed || !ed->fast_tabs)) return hipErrorInvalidValue;
     const size_t lds = MODE != MODE_DEMOSAIC ? TabsOf<PREC>::BYTES + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
-                                                   (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0)
+                                                   (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MASKS_PER_WORD : 0)
                                              : 0;
     // two builds of every fused kernel: with the vignette stage (coordinates hoisted per column / per row) and
     // without it (its code and registers compiled out: the plain kernel stays under 96 VGPRs)
@@ -1659,7 +1675,7 @@ static hipError_t run_hp(const LaunchCfg& cfg, const uint16_t* d_cfa, const RawP
     a.strips = (g.width + (uint32_t)raw.xo + HP_STRIP_W - 1) / HP_STRIP_W;
     constexpr uint32_t WPB = NT / 64;
     const size_t lds = (hp_fast_biased(NT, LDS_LUT, PREC) ? FAST_TABS_BIASED_AT : 0u) + TabsOf<PREC>::BYTES +
-                       (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) + (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
+                       (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) + (mode_multi(MODE) ? sizeof(MaskParams) * RPF_MASKS_PER_WORD : 0);
     const bool vign = ed->vign_strength != 0.0f;
     if (PREC && !ed->fast_tabs) return hipErrorInvalidValue;
     // k_hp reads the vignette's falloff from the tile's map (the API layer builds it when the slider leaves 0)
@@ -1906,6 +1922,7 @@ hipError_t launch_develop_packed(const LaunchCfg& cfg, const uint8_t* d_packed, 
     if (row_stride < need) return hipErrorInvalidValue;
     if ((uint64_t)row_stride * (g.rows + 4) > 0xffffffffull) return hipErrorInvalidValue;  // 32-bit row offsets
     if (ed.lens_strength != 0.0f || ed.flags != 0) return hipErrorInvalidValue;
+    if (ed.num_masks > RPF_MASKS_PER_WORD) return hipErrorInvalidValue;  // see launch_develop
     const PackedRows pk{bits, row_stride, order};
     switch (out_format) {
     // the CSI-2 group layout is a compile-time variant of the packed row loads (as a run-time branch per sample it cost
@@ -1929,6 +1946,8 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
     if (!d_cfa || !d_out) return hipErrorInvalidValue;
     if (ed.lens_strength != 0.0f) return hipErrorInvalidValue;  // needs the resampling pass (launch_apply)
     if (ed.flags != 0) return hipErrorInvalidValue;             // the Godot-legacy flavour lives in k_apply only
+    // more masks than one coverage word holds: demosaic, then the RGBA pass (launch_apply) — the caller's two launches
+    if (ed.num_masks > RPF_MASKS_PER_WORD) return hipErrorInvalidValue;
     switch (out_format) {
     case OUT_RGBA_F32: return develop_fmt<OUT_RGBA_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
     case OUT_RGB_F32: return develop_fmt<OUT_RGB_F32>(cfg, d_cfa, raw, g, ed, d_out, s);
@@ -1940,12 +1959,17 @@ hipError_t launch_develop(const LaunchCfg& cfg, const uint16_t* d_cfa, const Raw
 #endif  // RPF_TU != 2
 
 #if RPF_TU != 1
+// k_apply<SINGLE = 7> stages every mask's parameters in LDS: 48 B each behind the 28-KiB tables — 1024 masks are 48 KiB, and
+// a CU still runs four 256-thread workgroups.  Editors with more read them from device memory (SINGLE = 8).
+constexpr uint32_t WIDE_LDS_MASKS = 1024;
 template <bool LDS_LUT, bool LENS, int OUTFMT, int SINGLE, int PREC = 0>
 static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_t s)
 {
     constexpr int NT = LDS_LUT ? 1024 : 256;
+    // (SINGLE == 7: every mask's parameters, in steps of 64 masks so that few sizes occur)
     const size_t lds = TabsOf<PREC>::BYTES + (LDS_LUT ? (size_t)RPF_CURVE_RESOLUTION * 2 : 0) +
-                       (SINGLE == 0 || SINGLE == 6 ? sizeof(MaskParams) * RPF_MAX_MASKS : 0);
+                       (SINGLE == 0 || SINGLE == 6 ? sizeof(MaskParams) * RPF_MASKS_PER_WORD : 0) +
+                       (SINGLE == 7 ? sizeof(MaskParams) * ((a.ed.num_masks + 63u) / 64u * 64u) : 0);
     auto kernel = k_apply<NT, LDS_LUT, LENS, OUTFMT, SINGLE, PREC>;
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
@@ -1953,10 +1977,10 @@ static hipError_t run_apply(const LaunchCfg& cfg, const ApplyArgs& a, hipStream_
     // persistent grid-stride workgroups: exactly as many as are resident (registers and the 28-KiB table copy in
     // LDS decide; one more per CU would run as a second, mostly empty round)
     static std::atomic<int> resident_cache;
-    int resident = resident_cache.load(std::memory_order_relaxed);
+    int resident = SINGLE == 7 ? 0 : resident_cache.load(std::memory_order_relaxed);  // (7: the LDS size varies with the launch)
     if (resident == 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, NT, lds) != hipSuccess || resident < 1) resident = 1;
-        resident_cache.store(resident, std::memory_order_relaxed);
+        if (SINGLE != 7) resident_cache.store(resident, std::memory_order_relaxed);
     }
     size_t grid = (size_t)cfg.num_cus * (size_t)resident;
     const size_t need = (npix + NT * 2 - 1) / (NT * 2);
@@ -1970,6 +1994,14 @@ static hipError_t apply_fmt(const LaunchCfg& cfg, const ApplyArgs& a0, hipStream
 {
     // launches with user masks whose "main" has no brightness curve stage the first user mask's that has one (up to 8 masks;
     // variants 10 and 23, A/B: off) — as the fused develop launches do (develop_fmt)
+    // more masks than one coverage word holds: the general chain over further planes (exact arithmetic in either precision)
+    // (variant 24, A/B and the test of it: the parameters from device memory whatever the number of masks)
+    if (a0.ed.num_masks > RPF_MASKS_PER_WORD) {
+        const bool lens7 = a0.ed.lens_strength != 0.0f;
+        if (a0.ed.num_masks <= WIDE_LDS_MASKS && cfg.variant != 24)
+            return lens7 ? run_apply<false, true, OUTFMT, 7>(cfg, a0, s) : run_apply<false, false, OUTFMT, 7>(cfg, a0, s);
+        return lens7 ? run_apply<false, true, OUTFMT, 8>(cfg, a0, s) : run_apply<false, false, OUTFMT, 8>(cfg, a0, s);
+    }
     ApplyArgs a = a0;
     bool lut = needs_lds_lut(a.ed);
     if (!lut && a.ed.num_masks > 1 && a.ed.num_masks <= 8 && cfg.variant != 10 && cfg.variant != 23)
@@ -2152,7 +2184,7 @@ hipError_t launch_repack(const float* d_rgba, size_t npix, void* d_out, int out_
 hipError_t launch_combine_masks(const uint8_t* d_planes, uint32_t planes, size_t npix, uint16_t* d_bits, hipStream_t s)
 {
     if (npix == 0 || planes == 0) return hipSuccess;
-    if (!d_planes || !d_bits || planes > RPF_MAX_MASKS - 1) return hipErrorInvalidValue;
+    if (!d_planes || !d_bits || planes > 16) return hipErrorInvalidValue;
     const uint32_t grid = (uint32_t)((npix + 255) / 256 > 8192 ? 8192 : (npix + 255) / 256);
     hipLaunchKernelGGL(k_combine_masks, dim3(grid), dim3(256), 0, s, d_planes, planes, npix, d_bits);
     return hipGetLastError();

@@ -8,11 +8,13 @@ namespace rpf {
 
 // Edit state as the kernels see it (all device pointers owned by the caller).
 struct DeviceEdit {
-    MaskParams mp[RPF_MAX_MASKS];
+    MaskParams mp[RPF_MASKS_PER_WORD];  // the first 16 masks' ("main" + 15 user masks); all of them: mp_wide
     uint32_t num_masks;
     // One u16 per pixel of the tile: bit m - 1 set <=> user mask m covers the pixel (its binarised value is 1.0,
     // lib.rs:483-486); null when there are no user masks.  ONE load per pixel whatever the number of masks — per-mask u8
     // planes cost the kernel a dependent round trip to memory per mask per step.
+    // More than RPF_MASKS_PER_WORD masks: ceil(num_masks / 16) such planes, rows x width elements apart; bit j of plane
+    // g >= 1 <=> mask 16 g + j (rpf_chain.h WideMasks).
     const uint16_t* mask_bits;
     const uint16_t* bright;      // num_masks x 65536 u16, clamped (wgsl:188)
     const ushort4* hsl;          // num_masks x 65536 {hue, sat, light, 0}
@@ -40,6 +42,10 @@ struct DeviceEdit {
     // Which mask's brightness curve a launch that stages one in LDS (128 KiB: there is room for ONE) stages: 0 = "main"; a
     // user mask's index when "main"'s is the identity (chosen per launch by launch_develop: the first mask that has one)
     uint32_t lds_bright_mask;
+    // num_masks > RPF_MASKS_PER_WORD (the reference has no limit, lib.rs:481-499): every mask's parameters, in device
+    // memory (the kernel-argument segment holds 16).  Such an editor runs the RGBA pass (launch_apply), from a Bayer frame
+    // after the demosaic-only kernel; the fused kernels take up to 16 masks.  Null otherwise.
+    const MaskParams* mp_wide;
 };
 enum EditFlags : uint32_t { EF_LEGACY_VIGNETTE = 1u, EF_DECODE_INPUT = 2u };
 

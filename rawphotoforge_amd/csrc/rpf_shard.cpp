@@ -421,6 +421,9 @@ int prepare_band_launch(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_st
         return api_fail(RPF_ERR_INVALID_ARGUMENT, "lens distortion resamples the whole frame: it does not shard by rows");
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return api_fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
+    if (e->dev.num_masks > RPF_MASKS_PER_WORD)
+        return api_fail(RPF_ERR_INVALID_ARGUMENT, "the fused band kernel takes \"main\" + 15 user masks: with more, exchange the halo "
+                                                  "rows (rpf_shard_exchange), then rpf_dev_demosaic and rpf_dev_apply on the band");
     e->dev.flags = 0;
     e->foreign_streams = true;  // the launch goes to a stream of the caller's (api_editor_quiesce)
     b = BandLaunch{e->proc, e->geom, e->dev, static_cast<const unsigned char*>(d_band), (uint32_t)row_stride, bits, order,

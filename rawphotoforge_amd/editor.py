@@ -76,14 +76,10 @@ class InvalidArgument(PhotoEditorError):
     code = N.ERR_INVALID_ARGUMENT
 
 
-class TooManyMasks(PhotoEditorError):
-    code = N.ERR_TOO_MANY_MASKS
-
-
 _BY_CODE = {c.code: c for c in (FailedToReadImage, GpuComputeError, GpuInitializationError, MaskNotFound,
                                 MismatchedLengths, NotEnoughPoints, NotStrictlyIncreasing,
                                 MissingCurveOrControlPoints, InvalidCurveLength, MissingControlPoints,
-                                EmptyControlPoints, InvalidArgument, TooManyMasks)}
+                                EmptyControlPoints, InvalidArgument)}
 
 
 def _check(rc: int) -> None:

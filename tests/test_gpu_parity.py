@@ -546,11 +546,11 @@ def test_random_parameter_space_on_gpu(gpu):
 
 
 def test_sixteen_masks(gpu):
-    """RPF_MAX_MASKS masks (the reference has no limit; its UI uses a handful): every mask's curves and its
+    """RPF_FUSED_MASKS masks — the most the fused kernel takes: every mask's curves and its
     u8 plane are gathered from L2, only "main"'s brightness curve lives in LDS."""
     rng = np.random.default_rng(16)
     h, w = 40, 72
-    n = R.MAX_MASKS
+    n = R.FUSED_MASKS
     cfa = util.bayer_natural(h, w, seed=16)
     rp = util.raw_params()
     params = [util.random_params(rng, trivial_prob=0.3) for _ in range(n)]
@@ -565,8 +565,130 @@ def test_sixteen_masks(gpu):
         util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
     ed.apply_adjustments()
     assert_parity(ed.rgba(), O.develop(cfa, rp, params, masks=masks))
-    with pytest.raises(R.TooManyMasks):
-        ed.add_mask("one too many", masks[1])
+
+
+@pytest.mark.parametrize("n", [17, 32, 33, 50])
+def test_more_masks_than_the_fused_kernel_takes(gpu, n):
+    """The reference has no limit on masks (lib.rs:481-499).  Past RPF_FUSED_MASKS the coverage lies in one 16-bit plane per
+    16 masks and the parameters in device memory; a Bayer editor runs the demosaic-only kernel and the RGBA pass.  Counts
+    on both sides of a plane boundary; masks that cover nothing, everything, and a pixel alone; removing masks brings the
+    editor back under the boundary (the fused kernel again) with the slots moved."""
+    rng = np.random.default_rng(1000 + n)
+    h, w = 36, 70
+    cfa = util.bayer_natural(h, w, seed=n)
+    rp = util.raw_params()
+    params = [util.random_params(rng, trivial_prob=0.4) for _ in range(n)]
+    masks = np.ones((n, h, w), np.float32)
+    ed = bayer_editor(gpu, cfa, rp)
+    for m in range(1, n):
+        if m == 20:
+            mm = np.zeros((h, w), np.float32)                     # covers nothing
+        elif m == 21:
+            mm = np.ones((h, w), np.float32)                      # covers everything
+        elif m == n - 1:
+            mm = np.zeros((h, w), np.float32); mm[h // 2, w // 3] = 1.0   # the last mask: one pixel
+        else:
+            mm = (rng.random((h, w)) > 0.75).astype(np.float32)
+        ed.add_mask(f"m{m}", mm)
+        masks[m] = O.binarize_mask(mm)
+    for m, p in enumerate(params):
+        util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), O.develop(cfa, rp, params, masks=masks))
+    # the other output layouts read the same frame
+    want = O.develop(cfa, rp, params, masks=masks)
+    np.testing.assert_array_equal(ed.to_flat_vec_rgb().reshape(h, w, 3), want[..., :3])
+    np.testing.assert_array_equal(ed.to_rgb_array3_u8(), O.rgba_to_rgb_u8(want))
+    # a setter on a mask of a further plane
+    p_new = util.random_params(rng, trivial_prob=0.0)
+    params[n - 2] = p_new
+    util.configure_editor(ed, p_new, f"m{n - 2}", main=False)
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), O.develop(cfa, rp, params, masks=masks))
+    # remove masks from the front until the editor fits the fused kernel again: every later slot moves down
+    keep = [0] + list(range(n - (R.FUSED_MASKS - 1), n))
+    for m in range(1, n):
+        if m not in keep:
+            ed.remove_mask(f"m{m}")
+    assert ed.num_masks == R.FUSED_MASKS
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), O.develop(cfa, rp, [params[m] for m in keep], masks=masks[keep]))
+
+
+def test_many_masks_with_their_parameters_in_device_memory(gpu):
+    """Variant 24: the kernel editors with more than 1024 masks run (parameters read from device memory, not staged in LDS)."""
+    rng = np.random.default_rng(2424)
+    h, w, n = 30, 50, 21
+    img = rng.random((h, w, 3), dtype=np.float32)
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    params = [util.random_params(rng, trivial_prob=0.4) for _ in range(n)]
+    masks = np.ones((n, h, w), np.float32)
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    for m in range(1, n):
+        mm = (rng.random((h, w)) > 0.7).astype(np.float32)
+        ed.add_mask(f"m{m}", mm)
+        masks[m] = O.binarize_mask(mm)
+    for m, p in enumerate(params):
+        util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
+    gpu.set_kernel_variant(24)
+    try:
+        ed.apply_adjustments()
+        got = ed.rgba()
+    finally:
+        gpu.set_kernel_variant(0)
+    assert_parity(got, O.apply(rgba, params, masks=masks))
+
+
+def test_many_masks_on_an_rgb_editor_with_lens_and_vignette(gpu):
+    """40 masks through the reference's own pass (RGB input), with the lens resample and the vignette in front."""
+    rng = np.random.default_rng(4040)
+    h, w, n = 41, 67, 40
+    img = rng.random((h, w, 3), dtype=np.float32)
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    params = [util.random_params(rng, trivial_prob=0.4) for _ in range(n)]
+    params[0].vignette = -40
+    masks = np.ones((n, h, w), np.float32)
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    for m in range(1, n):
+        mm = (rng.random((h, w)) > 0.8).astype(np.float32)
+        ed.add_mask(f"m{m}", mm)
+        masks[m] = O.binarize_mask(mm)
+    for lens in (0, 35):
+        params[0].lens_distortion = lens
+        for m, p in enumerate(params):
+            util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
+        ed.apply_adjustments()
+        assert_parity(ed.rgba(), O.apply(rgba, params, masks=masks))
+
+
+def test_fused_tile_entry_points_name_the_two_launches_for_many_masks(gpu):
+    """rpf_dev_develop takes "main" + 15 user masks; with more it says which two launches compute the same bits — and they do."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(77)
+    h, w, n = 32, 64, 18
+    cfa = util.bayer_natural(h, w, seed=77)
+    rp = util.raw_params()
+    params = [util.random_params(rng, trivial_prob=0.5) for _ in range(n)]
+    masks = np.ones((n, h, w), np.float32)
+    ed = R.PhotoEditor.for_tile(gpu, w, h, 0, h)
+    for m in range(1, n):
+        mm = (rng.random((h, w)) > 0.6).astype(np.float32)
+        ed.add_mask(f"m{m}", mm)
+        masks[m] = O.binarize_mask(mm)
+    for m, p in enumerate(params):
+        util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
+    band = np.zeros((h + 4, w), np.uint16)   # rows -2 .. h + 1 (outside the frame: never read, the kernel reflects)
+    band[2:-2] = cfa
+    d_band = torch.from_numpy(band.view(np.int16)).cuda()
+    d_out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(R.InvalidArgument, match="rpf_dev_demosaic"):
+        ed.dev_develop(d_band.data_ptr(), util.to_raw(rp), d_out.data_ptr(), R.OUT_RGBA_F32, s)
+    d_lin = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    R.dev_demosaic(gpu, d_band.data_ptr(), util.to_raw(rp), w, h, 0, h, d_lin.data_ptr(), s)
+    ed.dev_apply(d_lin.data_ptr(), d_out.data_ptr(), R.OUT_RGBA_F32, s)
+    torch.cuda.synchronize()
+    assert_parity(d_out.cpu().numpy(), O.develop(cfa, rp, params, masks=masks))
 
 
 def test_editors_share_a_processor_and_interleave(gpu):

@@ -106,3 +106,27 @@ def test_demosaic_formulas_with_carried_powers_of_two_equal_the_specification():
     util.twin().twin_mhc(C.c_size_t(n), P(c), P(s1), P(e1), P(d), P(v2), P(h2), *[o.ctypes.data_as(C.POINTER(C.c_float)) for o in outs])
     for got, want, name in zip(outs, (want_cross, want_diag, want_h, want_v), ("cross", "diag", "horiz", "vert")):
         assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want, f).view(np.uint32)), name
+
+
+def test_coverage_planes_any_number_of_masks():
+    """The reference has no limit on masks (lib.rs:481-499).  The chain under real coverage, with the product's layout — one
+    16-bit plane per 16 masks, the masks past the first word through edit_chain's WideMasks (k_apply<SINGLE = 7>) — against
+    the oracle's f32 mask planes: bit-exact on both sides of every plane boundary."""
+    for n_masks in (2, 15, 16, 17, 31, 32, 33, 50):
+        rng = np.random.default_rng(700 + n_masks)
+        n = 6_000
+        rgb = _pixels(n, 800 + n_masks)
+        params = [util.random_params(rng, trivial_prob=0.4) for _ in range(n_masks)]
+        for p in params:
+            p.vignette = 0
+            p.lens_distortion = 0
+        masks = np.ones((n_masks, 1, n), np.float32)
+        for m in range(1, n_masks):
+            masks[m, 0] = (rng.random(n) > (0.97 if m % 7 == 3 else 0.6)).astype(np.float32)
+        if n_masks > 20:
+            masks[20] = 0.0   # a mask that covers nothing
+            masks[19] = 1.0   # and one that covers everything
+        img = np.concatenate([rgb, np.ones((n, 1), np.float32)], 1).reshape(1, n, 4)
+        want = O.apply(img, params, masks=masks).reshape(n, 4)
+        got = util.twin_apply_masked(rgb, params, masks)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), n_masks

@@ -305,6 +305,38 @@ void twin_apply(const float* rgb, size_t npix, const twin_edit_params* ep, uint3
 {
     twin_apply_mode(rgb, npix, ep, num_masks, bright, hue, sat, light, rgba_out, 0);
 }
+
+// The exact chain under real coverage: `planes` = ceil(num_masks / 16) planes of npix u16 as the product lays them out
+// (rpf_launch.h DeviceEdit::mask_bits: plane 0 bit j = user mask j + 1, plane g >= 1 bit j = mask 16 g + j); more than 16
+// masks go through edit_chain's WideMasks as in k_apply<SINGLE = 7>.
+void twin_apply_masked(const float* rgb, size_t npix, const twin_edit_params* ep, uint32_t num_masks, const int32_t* bright,
+                       const int32_t* hue, const int32_t* sat, const int32_t* light, const uint16_t* planes, float* rgba_out)
+{
+    std::vector<rpf::MaskParams> mp(num_masks);
+    for (uint32_t m = 0; m < num_masks; ++m) {
+        rpf::EditParameters p;
+        p.exposure = ep[m].exposure; p.contrast = ep[m].contrast; p.shadow = ep[m].shadow;
+        p.highlight = ep[m].highlight; p.black = ep[m].black; p.white = ep[m].white;
+        p.wb_temperature = ep[m].wb_temperature; p.wb_tint = ep[m].wb_tint;
+        const int32_t* src[4] = {bright, hue, sat, light};
+        for (int c = 0; c < 4; ++c)
+            p.curve[c].assign(src[c] + (size_t)m * RPF_CURVE_RESOLUTION, src[c] + (size_t)(m + 1) * RPF_CURVE_RESOLUTION);
+        mp[m] = rpf::make_mask_params(p);
+    }
+    HostLuts L{bright, hue, sat, light};
+    const rpf::MathTables& T = tabs();
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)npix; ++i) {
+        float r[1] = {rgb[i * 3]}, g[1] = {rgb[i * 3 + 1]}, b[1] = {rgb[i * 3 + 2]};
+        const uint32_t act[1] = {1u | ((uint32_t)planes[i] << 1)};
+        if (num_masks > RPF_MASKS_PER_WORD)
+            rpf::edit_chain<1>(r, g, b, act, mp.data(), (uint32_t)RPF_MASKS_PER_WORD, L, T,
+                               rpf::WideMasks<1>{num_masks, planes, npix, {(size_t)i}});
+        else
+            rpf::edit_chain<1>(r, g, b, act, mp.data(), num_masks, L, T);
+        rgba_out[i * 4] = r[0]; rgba_out[i * 4 + 1] = g[0]; rgba_out[i * 4 + 2] = b[0]; rgba_out[i * 4 + 3] = 1.0f;
+    }
+}
 }
 
 // ---- the demosaic formulas as the kernels evaluate them (rpf_chain.h mhc_*: powers of two carried into fma) ---------
@@ -342,9 +374,8 @@ extern "C" int twin_state_exercise(void)
     fails += st.set_curve(RPF_CURVE_HUE, xs, 4, nullptr, 0, nullptr, 0, nullptr).code != RPF_ERR_INTERP_INVALID_CURVE_LENGTH;
     fails += st.set_curve(RPF_CURVE_HUE, nullptr, 0, nullptr, 0, nullptr, 0, nullptr).code != RPF_ERR_INTERP_MISSING_CURVE_OR_CONTROL_POINTS;
     std::vector<float> m(35, 0.5f);
-    for (int i = 0; i < RPF_MAX_MASKS - 1; ++i) fails += !st.add_mask(("m" + std::to_string(i)).c_str(), m.data());
-    fails += st.add_mask("overflow", m.data()).code != RPF_ERR_TOO_MANY_MASKS;
-    fails += !st.remove_mask("m3") || !st.remove_mask("main") || st.masks.size() != (size_t)RPF_MAX_MASKS - 1;
+    for (int i = 0; i < 40; ++i) fails += !st.add_mask(("m" + std::to_string(i)).c_str(), m.data());  // lib.rs:481-499: no limit
+    fails += !st.remove_mask("m3") || !st.remove_mask("main") || st.masks.size() != (size_t)40;
     for (auto& mk : st.masks) (void)rpf::make_mask_params(mk.params);
     st.reset();
     fails += st.masks.size() != 1 || st.masks[0].params.wb_temperature != 0;

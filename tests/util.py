@@ -96,6 +96,35 @@ def twin_apply(rgb, masks_params, fused=False, fast=False) -> np.ndarray:
     return out
 
 
+def mask_bit_planes(masks) -> np.ndarray:
+    """Binarised masks (num_masks, ..., "main" first) -> the product's coverage planes (rpf_launch.h DeviceEdit::mask_bits):
+    one u16 per pixel and 16 masks; plane 0 bit j = user mask j + 1, plane g >= 1 bit j = mask 16 g + j."""
+    m = np.asarray(masks)
+    n = m.shape[0]
+    flat = (m.reshape(n, -1) == 1.0)
+    planes = np.zeros(((n + 15) // 16, flat.shape[1]), np.uint16)
+    for k in range(1, n):
+        g, j = (0, k - 1) if k < 16 else (k // 16, k % 16)
+        planes[g] |= (flat[k].astype(np.uint16) << np.uint16(j))
+    return planes
+
+
+def twin_apply_masked(rgb, masks_params, masks) -> np.ndarray:
+    """twin_apply under real coverage (any number of masks): the exact chain with the product's coverage-plane layout."""
+    n = len(masks_params)
+    a = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+    ep = (O.EditParamsC * n)(*[p.to_c() for p in masks_params])
+    luts = [np.stack([np.asarray(getattr(p, nm), np.int32) for p in masks_params])
+            for nm in ("brightness_tone_curve", "hue_tone_curve", "saturation_tone_curve", "lightness_tone_curve")]
+    planes = np.ascontiguousarray(mask_bit_planes(masks))
+    assert planes.shape[1] == a.shape[0]
+    out = np.empty((a.shape[0], 4), np.float32)
+    twin().twin_apply_masked(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.shape[0]), ep, C.c_uint32(n),
+                             *[l.ctypes.data_as(C.c_void_p) for l in luts], planes.ctypes.data_as(C.c_void_p),
+                             out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def ulp_diff(a, b) -> np.ndarray:
     """Distance in units in the last place between two float32 arrays (monotone integer mapping)."""
     def key(x):
