@@ -49,7 +49,7 @@ def check_fast(got_fast, want, what, params):
         print(f"FAST out of bounds, case {n} {what}: {far:.4f} of the pixels beyond 1e-5, finite {np.isfinite(g).all()}", flush=True)
 while time.time() < t_end:
     h, w = int(rng.integers(3, 140)), int(rng.integers(3, 420))
-    n_masks = int(rng.choice([1, 1, 1, 2, 3]))
+    n_masks = int(rng.choice([1, 1, 1, 2, 3])) if rng.random() > 0.04 else int(rng.integers(15, 40))   # now and then: past one coverage word
     params = [util.random_params(rng) for _ in range(n_masks)]
     params[0].vignette = 0 if rng.random() < 0.4 else int(rng.integers(-100, 101))
     masks = np.ones((n_masks, h, w), np.float32)
