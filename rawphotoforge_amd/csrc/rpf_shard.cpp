@@ -121,6 +121,9 @@ struct BandLaunch {
     RawParamsDev raw;
     void* out;
     int out_format;
+    // More masks than the fused band kernel takes (rpf_launch.h DeviceEdit::mp_wide): the band's linear RGBA32F, an
+    // intermediate of the EDITOR's (rows x width), between the demosaic-only kernel and the RGBA pass.  Null otherwise.
+    float* linear;
 };
 }  // namespace
 
@@ -211,6 +214,14 @@ hipError_t launch_band(const BandLaunch& b, hipStream_t stream, hipEvent_t stop_
     if (reserve_cus > 0 && cfg.num_cus > 4 * reserve_cus) cfg.num_cus -= reserve_cus;
     cfg.stop_event = stop_event;
     cfg.start_event = start_event;
+    if (b.linear) {  // two launches, the same bits (rpf_api.cpp rpf_apply_adjustments does the same for a whole frame)
+        cfg.stop_event = cfg.start_event = nullptr;
+        hipError_t e = start_event ? hipEventRecord(start_event, stream) : hipSuccess;
+        if (e == hipSuccess) e = launch_demosaic(cfg, reinterpret_cast<const uint16_t*>(b.band), b.raw, b.geom, b.linear, stream);
+        if (e == hipSuccess) e = launch_apply(cfg, b.linear, b.geom, b.dev, b.out, b.out_format, stream);
+        if (e == hipSuccess && stop_event) e = hipEventRecord(stop_event, stream);
+        return e;
+    }
     if (b.bits)
         return launch_develop_packed(cfg, b.band, b.row_stride, b.bits, b.order, b.raw, b.geom, b.dev, b.out, b.out_format, stream);
     return launch_develop(cfg, reinterpret_cast<const uint16_t*>(b.band), b.raw, b.geom, b.dev, b.out, b.out_format, stream);
@@ -421,13 +432,20 @@ int prepare_band_launch(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_st
         return api_fail(RPF_ERR_INVALID_ARGUMENT, "lens distortion resamples the whole frame: it does not shard by rows");
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return api_fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
-    if (e->dev.num_masks > RPF_MASKS_PER_WORD)
-        return api_fail(RPF_ERR_INVALID_ARGUMENT, "the fused band kernel takes \"main\" + 15 user masks: with more, exchange the halo "
-                                                  "rows (rpf_shard_exchange), then rpf_dev_demosaic and rpf_dev_apply on the band");
+    float* linear = nullptr;
+    if (e->dev.num_masks > RPF_MASKS_PER_WORD) {  // the band's steps become demosaic + RGBA pass (launch_band)
+        if (bits)
+            return api_fail(RPF_ERR_INVALID_ARGUMENT, "a packed band with more than \"main\" + 15 user masks: unpack it first "
+                                                      "(rpf_dev_unpack_bayer), then the u16 band");
+        if (!e->d_original)
+            HIP_TRY(hipMalloc((void**)&e->d_original, (size_t)e->geom.rows * e->geom.width * 4 * sizeof(float)));
+        linear = e->d_original;
+        e->original_valid = false;  // (a whole-frame Bayer editor keeps its demosaiced frame there: no longer that)
+    }
     e->dev.flags = 0;
     e->foreign_streams = true;  // the launch goes to a stream of the caller's (api_editor_quiesce)
     b = BandLaunch{e->proc, e->geom, e->dev, static_cast<const unsigned char*>(d_band), (uint32_t)row_stride, bits, order,
-                   make_raw_params(*raw), d_out, out_format};
+                   make_raw_params(*raw), d_out, out_format, linear};
     return RPF_OK;
 }
 }  // namespace

@@ -135,6 +135,58 @@ def test_rccl_exchange_with_itself_as_neighbour(gpu):
 
 
 @gpu_only
+def test_sharded_step_with_more_masks_than_the_fused_kernel_takes(gpu):
+    """A band whose editor holds 20 masks (the reference has no limit, lib.rs:481-499): the step becomes the halo exchange, the
+    demosaic-only kernel and the RGBA pass on the band (rpf_shard.cpp launch_band) — synchronous and handed to the shard's thread,
+    timed — and a packed band says what to do instead."""
+    torch = pytest.importorskip("torch")
+    w, rows, n = 260, 64, 20
+    band_rows = util.bayer_natural(rows, w, seed=19)
+    frame = np.concatenate([band_rows[:2], band_rows, band_rows[-2:]])   # the rank is its own neighbour: y0 = 2
+    h = frame.shape[0]
+    rp = util.raw_params()
+    rng = np.random.default_rng(20)
+    params = [util.random_params(rng, trivial_prob=0.4) for _ in range(n)]
+    for p in params:
+        p.lens_distortion = 0
+    raw_masks = [(rng.random((rows, w)) > 0.7).astype(np.float32) for _ in range(n - 1)]
+    masks = np.ones((n, rows, w), np.float32)   # band-sized, like the editor's
+    for m in range(1, n):
+        masks[m] = O.binarize_mask(raw_masks[m - 1])
+    want = O.develop(frame, rp, params, masks=masks, y0=2, rows=rows)
+
+    def configure(e):
+        for m in range(1, n):
+            e.add_mask(f"m{m}", raw_masks[m - 1])
+        for m, p in enumerate(params):
+            util.configure_editor(e, p, None if m == 0 else f"m{m}", main=(m == 0))
+    pad = np.full((rows + 4, w), 999, np.uint16)
+    pad[2:-2] = band_rows
+    band = torch.from_numpy(pad.view(np.int16)).cuda()
+    out = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+    shard = R.Shard(gpu, None, 0, 1)
+    shard.set_neighbours(0, 0)
+    sd = tiles.ShardedDeveloper(gpu, w, h, 2, rows, util.to_raw(rp), configure, shard=shard)
+    assert sd.ed.num_masks == n
+    sd.step(band, out)
+    torch.cuda.synchronize()
+    _exact(out.cpu().numpy(), want)
+    out.zero_()
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        sd.step_async(band, out, stream=s, timed=True)
+    shard.drain(s)
+    torch.cuda.synchronize()
+    _exact(out.cpu().numpy(), want)
+    launches, total_ms = shard.timing()
+    assert launches == 3 and total_ms > 0
+    packed = torch.zeros((rows + 4, (w * 12 + 7) // 8), dtype=torch.uint8, device="cuda")
+    sdp = tiles.ShardedDeveloper(gpu, w, h, 2, rows, util.to_raw(rp), configure, shard=shard, packed=(12, packed.shape[1], R.PACK_MSB_FIRST))
+    with pytest.raises(R.InvalidArgument, match="unpack"):
+        sdp.step(packed, out, exchange=False)
+
+
+@gpu_only
 def test_two_independent_step_pipelines(gpu):
     """rpf_shard_develop_async: steps handed to the shards' own threads.  Two shards (two one-rank communicators, each rank
     its own neighbour), two streams, two band buffers with DIFFERENT frames and garbage halos, frames alternating for ten
