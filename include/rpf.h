@@ -62,9 +62,9 @@ extern "C" {
 /* An editor holds any number of masks (lib.rs:481-499 has no limit).  Up to this many — "main" + 15 user masks — run the
  * fused kernels from a Bayer frame: their coverage is ONE 16-bit word per pixel and their parameters travel with the launch.
  * With more, rpf_apply_adjustments runs the demosaic-only kernel and the RGBA pass (one 16-bit coverage plane per 16 masks,
- * parameters in device memory; the same bits) and so does a sharded step (rpf_shard_develop*; u16 bands; the band's linear
- * intermediate belongs to the editor, which therefore serves one stream at a time then); the fused tile entry points
- * (rpf_dev_develop*) return RPF_ERR_INVALID_ARGUMENT: rpf_dev_demosaic + rpf_dev_apply are the two launches there. */
+ * parameters in device memory; the same bits) and so do rpf_dev_develop and a sharded step (rpf_shard_develop*) on a u16 band:
+ * the band's linear intermediate belongs to the editor, which therefore serves one stream at a time then.  Packed bands
+ * (rpf_dev_develop_packed, packed sharded steps) return RPF_ERR_INVALID_ARGUMENT with more than 16 masks: unpack first. */
 #define RPF_FUSED_MASKS 16
 
 typedef enum rpf_status {

@@ -972,11 +972,18 @@ int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* 
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only: use rpf_dev_demosaic, "
                                               "then rpf_dev_apply, for the Godot-legacy flavour");
-    if (e->dev.num_masks > RPF_MASKS_PER_WORD)
-        return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel takes \"main\" + 15 user masks: with more, rpf_dev_demosaic into a "
-                                              "buffer of yours, then rpf_dev_apply (the same bits)");
     if ((hipStream_t)stream != e->stream) e->foreign_streams = true;
     e->dev.flags = 0;
+    if (e->dev.num_masks > RPF_MASKS_PER_WORD) {
+        // More masks than the fused kernel takes: the demosaic-only kernel into the editor's own linear tile, then the RGBA
+        // pass — the same bits (rpf_apply_adjustments and a sharded step do the same).  That tile is the editor's: with so many
+        // masks it serves one stream at a time.
+        if (!e->d_original) HIP_TRY(hipMalloc((void**)&e->d_original, npix_of(e) * 4 * sizeof(float)));
+        e->original_valid = false;
+        HIP_TRY(launch_demosaic(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->d_original, (hipStream_t)stream));
+        HIP_TRY(launch_apply(cfg_of(e->proc), e->d_original, e->geom, e->dev, d_out, out_format, (hipStream_t)stream));
+        return ok();
+    }
     HIP_TRY(launch_develop(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->dev, d_out, out_format,
                            (hipStream_t)stream));
     return ok();
@@ -1009,8 +1016,8 @@ int rpf_dev_develop_packed(rpf_editor* e, const uint8_t* d_packed, size_t row_st
     if (e->flavour != RPF_FLAVOUR_ACTIVE)
         return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel implements the active shader only");
     if (e->dev.num_masks > RPF_MASKS_PER_WORD)
-        return fail(RPF_ERR_INVALID_ARGUMENT, "the fused kernel takes \"main\" + 15 user masks: with more, rpf_dev_unpack_bayer and "
-                                              "rpf_dev_demosaic into buffers of yours, then rpf_dev_apply (the same bits)");
+        return fail(RPF_ERR_INVALID_ARGUMENT, "packed rows with more than \"main\" + 15 user masks: rpf_dev_unpack_bayer first, then "
+                                              "rpf_dev_develop on the u16 band (the same bits)");
     if ((hipStream_t)stream != e->stream) e->foreign_streams = true;
     e->dev.flags = 0;
     HIP_TRY(launch_develop_packed(cfg_of(e->proc), d_packed, (uint32_t)row_stride, bits, order, make_raw_params(*raw), e->geom,

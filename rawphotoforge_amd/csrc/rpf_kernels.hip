@@ -6,7 +6,9 @@
 //                              shipped since round 3 for launches with only "main"
 //   k_stream<MODE_DEVELOP...> the same chain, column-per-lane front end: packed input, launches with user masks
 //   k_tile<...>               the same two, LDS-tile front end (variant 1; the first design, kept for A/B)
-//   k_apply                   RGBA32F -> RGBA32F, wgsl main only   (what the reference's wgpu pass does)
+//   k_apply                   RGBA32F -> RGBA32F, wgsl main only   (what the reference's wgpu pass does); its SINGLE = 7 / 8
+//                              specialisations serve editors with more masks than one coverage word holds (any number:
+//                              lib.rs:481-499 has no limit) — from a Bayer frame after the demosaic-only kernel
 //   k_hp / k_stream / k_apply <..., PREC = 1>: the RPF_PRECISION_FAST specialisations (binary32-only builtins, rpf_fast.h;
 //                              the default, PREC = 0, evaluates every builtin correctly rounded and is the parity gate)
 //

@@ -661,8 +661,9 @@ def test_many_masks_on_an_rgb_editor_with_lens_and_vignette(gpu):
         assert_parity(ed.rgba(), O.apply(rgba, params, masks=masks))
 
 
-def test_fused_tile_entry_points_name_the_two_launches_for_many_masks(gpu):
-    """rpf_dev_develop takes "main" + 15 user masks; with more it says which two launches compute the same bits — and they do."""
+def test_tile_entry_point_with_many_masks(gpu):
+    """rpf_dev_develop with more masks than the fused kernel takes: the demosaic-only kernel into the editor's linear tile, then the
+    RGBA pass — and the caller's own two launches give the same bits; a packed band is refused with the remedy."""
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(77)
     h, w, n = 32, 64, 18
@@ -682,13 +683,23 @@ def test_fused_tile_entry_points_name_the_two_launches_for_many_masks(gpu):
     d_band = torch.from_numpy(band.view(np.int16)).cuda()
     d_out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    with pytest.raises(R.InvalidArgument, match="rpf_dev_demosaic"):
-        ed.dev_develop(d_band.data_ptr(), util.to_raw(rp), d_out.data_ptr(), R.OUT_RGBA_F32, s)
+    want = O.develop(cfa, rp, params, masks=masks)
+    ed.dev_develop(d_band.data_ptr(), util.to_raw(rp), d_out.data_ptr(), R.OUT_RGBA_F32, s)
+    torch.cuda.synchronize()
+    assert_parity(d_out.cpu().numpy(), want)
+    d_u8 = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    ed.dev_develop(d_band.data_ptr(), util.to_raw(rp), d_u8.data_ptr(), R.OUT_RGB_U8, s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_u8.cpu().numpy(), O.rgba_to_rgb_u8(want))
+    d_packed = torch.zeros((h + 4, (w * 12 + 7) // 8), dtype=torch.uint8, device="cuda")
+    with pytest.raises(R.InvalidArgument, match="rpf_dev_unpack_bayer"):
+        ed.dev_develop_packed(d_packed.data_ptr(), d_packed.shape[1], 12, util.to_raw(rp), d_out.data_ptr(), R.OUT_RGBA_F32, s)
+    d_out.zero_()
     d_lin = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
     R.dev_demosaic(gpu, d_band.data_ptr(), util.to_raw(rp), w, h, 0, h, d_lin.data_ptr(), s)
     ed.dev_apply(d_lin.data_ptr(), d_out.data_ptr(), R.OUT_RGBA_F32, s)
     torch.cuda.synchronize()
-    assert_parity(d_out.cpu().numpy(), O.develop(cfa, rp, params, masks=masks))
+    assert_parity(d_out.cpu().numpy(), want)
 
 
 def test_editors_share_a_processor_and_interleave(gpu):
