@@ -6,6 +6,14 @@ import argparse
 import os
 import sys
 
+
+def report(text):
+    """One line to the pipe the ranks share, as ONE write (a pipe write of up to PIPE_BUF bytes is not split): text and newline
+    written separately let another rank's line land between them."""
+    sys.stdout.flush()
+    os.write(1, (text.replace("\n", " ")[:3900] + "\n").encode())
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -81,8 +89,7 @@ def main():
         if rank == 1:
             assert err is not None and dt < 10.0, (err, dt)
             assert "rank 1 of" in err and "halo exchange" in err and "not enqueued within 1500 ms" in err, err
-        print(f"rank {rank} wedge: {'deadline fired after %.1f s: %s' % (dt, err) if err else 'no error (%.1f s)' % dt}", flush=True)
-        sys.stdout.flush()
+        report(f"rank {rank} wedge: {'deadline fired after %.1f s: %s' % (dt, err) if err else 'no error (%.1f s)' % dt}")
         os._exit(0)   # the stuck thread sits in the stand-in until ITS timeout: leave without joining it
 
     # 1. exchange, then one launch, on one stream (rpf_shard_develop) — both frames through shard 0
@@ -129,7 +136,7 @@ def main():
     torch.cuda.synchronize()
     for s in shards:
         s.close()
-    print(f"rank {rank} ok: band [{y0}, {y0 + rows}) of {W}x{H}, serial + pingpong + setters-while-queued bit-identical to the oracle", flush=True)
+    report(f"rank {rank} ok: band [{y0}, {y0 + rows}) of {W}x{H}, serial + pingpong + setters-while-queued bit-identical to the oracle")
     dist.destroy_process_group()
 
 

@@ -352,9 +352,7 @@ def test_bench_two_ranks_rehearsal_and_rccl_fallback(tmp_path):
            "--backend", "gloo"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    r = json.loads(lines[0])
+    r = util.bench_line(out.stdout)
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["mode"] == "strong" and r["config"]["world_size"] == 2
     assert r["config"]["backend"] == "gloo" and "REHEARSAL" in r["config"]["workload"] and "ONE 6000x4000 frame" in r["config"]["workload"]
     assert [x["band"] for x in r["config"]["ranks"]] == [[0, 2000], [2000, 2000]]

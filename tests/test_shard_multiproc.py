@@ -5,8 +5,8 @@ POSIX shared memory, loaded through rpf_shard.cpp's RPF_RCCL_LIB hook) stands in
 communicators of the two-pipeline schedule, rpf_shard_develop / rpf_shard_develop_async and bench.py's library branch run end
 to end with one process per rank, bit-identical to the oracle's bands.  Also here: the bounded waits (a wedged exchange ends
 in an error that names the rank, not in a hang) and setters / destroy while async steps are still queued."""
-import json
 import os
+import re
 import subprocess
 import sys
 
@@ -32,8 +32,9 @@ def test_sharded_step_with_real_processes(gpu, world):
     then a curve setter and add_mask while async steps are queued, and an editor destroyed with steps queued."""
     out = _run(world, [os.path.join(ROOT, "tests", "mp_shard_worker.py")], 29541 + world)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    oks = [l for l in out.stdout.splitlines() if " ok: band " in l]
-    assert len(oks) == world, out.stdout[-2000:]
+    # (by rank, over the whole text: the ranks share one pipe, and two of them may land on one line)
+    oks = {int(r) for r in re.findall(r"rank (\d+) ok: band ", out.stdout)}
+    assert oks == set(range(world)), out.stdout[-2000:]
 
 
 def test_a_wedged_exchange_ends_in_an_error_not_a_hang(gpu):
@@ -42,8 +43,8 @@ def test_a_wedged_exchange_ends_in_an_error_not_a_hang(gpu):
     out = _run(2, [os.path.join(ROOT, "tests", "mp_shard_worker.py"), "--mode", "wedge", "--width", "1024", "--height", "256"],
                29549, {"RPF_STANDIN_DROP_SENDS_FROM": "0", "RPF_STANDIN_TIMEOUT_MS": "6000"}, timeout=300)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    line = [l for l in out.stdout.splitlines() if l.startswith("rank 1 wedge")]
-    assert line and "deadline fired" in line[0] and "rank 1 of 2" in line[0], out.stdout[-2000:]
+    line = re.search(r"rank 1 wedge: ([^\n]*)", out.stdout)
+    assert line and "deadline fired" in line.group(1) and "rank 1 of 2" in line.group(1), out.stdout[-2000:]
 
 
 @pytest.mark.parametrize("schedule", ["serial", "pingpong"])
@@ -54,9 +55,7 @@ def test_bench_library_branch_with_two_processes(gpu, schedule):
                    "gloo", "--exchange", "rccl", "--schedule", schedule], 29551 + (schedule == "serial"),
                {"RPF_BENCH_TRY_RCCL": "1"})
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    r = json.loads(lines[0])
+    r = util.bench_line(out.stdout)   # ONE line, from rank 0
     c = r["config"]
     assert r["n_gpus"] == 2 and c["world_size"] == 2 and c["mode"] == "strong" and c["schedule"] == schedule
     assert "librpf_hip.so" in c["exchange"] and "fallback" not in c["exchange"]

@@ -96,6 +96,16 @@ def twin_apply(rgb, masks_params, fused=False, fast=False) -> np.ndarray:
     return out
 
 
+def bench_line(stdout: str) -> dict:
+    """THE JSON line of a bench.py run from the text of a pipe that several ranks may have written to (another rank's message
+    can land on the same line in front of it): exactly one object starting with "metric", parsed from where it starts."""
+    import json
+    import re
+    starts = [m.start() for m in re.finditer(re.escape('{"metric"'), stdout)]
+    assert len(starts) == 1, stdout[-2000:]
+    return json.JSONDecoder().raw_decode(stdout[starts[0]:])[0]
+
+
 def mask_bit_planes(masks) -> np.ndarray:
     """Binarised masks (num_masks, ..., "main" first) -> the product's coverage planes (rpf_launch.h DeviceEdit::mask_bits):
     one u16 per pixel and 16 masks; plane 0 bit j = user mask j + 1, plane g >= 1 bit j = mask 16 g + j."""
