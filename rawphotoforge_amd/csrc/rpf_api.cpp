@@ -464,7 +464,7 @@ void rpf_editor_destroy(rpf_editor* e)
         // than freed under a thread that will still touch it; the caller has been told (rpf_shard_flush / _drain failed).
         if (api_editor_quiesce(e) != RPF_OK) return;
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits, e->d_mp_wide,
+        void* bufs[] = {e->d_cfa, e->d_original, e->d_image, e->d_scratch, e->d_bright, e->d_hsl, e->d_masks, e->d_mask_bits, e->d_mp_wide, e->d_linear_tile,
                         e->d_vign_falloff, e->d_hue_fused_alloc};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
@@ -978,10 +978,9 @@ int rpf_dev_develop(rpf_editor* e, const uint16_t* d_cfa, const rpf_raw_params* 
         // More masks than the fused kernel takes: the demosaic-only kernel into the editor's own linear tile, then the RGBA
         // pass — the same bits (rpf_apply_adjustments and a sharded step do the same).  That tile is the editor's: with so many
         // masks it serves one stream at a time.
-        if (!e->d_original) HIP_TRY(hipMalloc((void**)&e->d_original, npix_of(e) * 4 * sizeof(float)));
-        e->original_valid = false;
-        HIP_TRY(launch_demosaic(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->d_original, (hipStream_t)stream));
-        HIP_TRY(launch_apply(cfg_of(e->proc), e->d_original, e->geom, e->dev, d_out, out_format, (hipStream_t)stream));
+        if (!e->d_linear_tile) HIP_TRY(hipMalloc((void**)&e->d_linear_tile, npix_of(e) * 4 * sizeof(float)));
+        HIP_TRY(launch_demosaic(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->d_linear_tile, (hipStream_t)stream));
+        HIP_TRY(launch_apply(cfg_of(e->proc), e->d_linear_tile, e->geom, e->dev, d_out, out_format, (hipStream_t)stream));
         return ok();
     }
     HIP_TRY(launch_develop(cfg_of(e->proc), d_cfa, make_raw_params(*raw), e->geom, e->dev, d_out, out_format,

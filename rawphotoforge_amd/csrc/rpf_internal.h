@@ -53,6 +53,9 @@ struct rpf_editor {
     uint16_t* d_mask_bits = nullptr;  // what the kernels read: one u16 of mask bits per pixel, combined on the device
                                       // (more than 16 masks: one such plane per 16 masks, rpf_launch.h DeviceEdit::mask_bits)
     uint32_t mask_bit_planes = 0;     // planes d_mask_bits holds room for
+    // rpf_dev_develop / a sharded step with more than 16 masks: the band's linear RGBA32F between the demosaic-only kernel and
+    // the RGBA pass (rows x width; a buffer of its own — d_original is an RGB editor's IMAGE, not a scratch)
+    float* d_linear_tile = nullptr;
     rpf::MaskParams* d_mp_wide = nullptr;  // every mask's parameters, for editors with more than 16 masks (DeviceEdit::mp_wide)
     uint32_t mp_wide_capacity = 0;
     // one mask with non-trivial hue / saturation / lightness curves: the fused hue table and what it was built from

@@ -437,10 +437,9 @@ int prepare_band_launch(rpf_shard* s, rpf_editor* e, void* d_band, size_t row_st
         if (bits)
             return api_fail(RPF_ERR_INVALID_ARGUMENT, "a packed band with more than \"main\" + 15 user masks: unpack it first "
                                                       "(rpf_dev_unpack_bayer), then the u16 band");
-        if (!e->d_original)
-            HIP_TRY(hipMalloc((void**)&e->d_original, (size_t)e->geom.rows * e->geom.width * 4 * sizeof(float)));
-        linear = e->d_original;
-        e->original_valid = false;  // (a whole-frame Bayer editor keeps its demosaiced frame there: no longer that)
+        if (!e->d_linear_tile)
+            HIP_TRY(hipMalloc((void**)&e->d_linear_tile, (size_t)e->geom.rows * e->geom.width * 4 * sizeof(float)));
+        linear = e->d_linear_tile;
     }
     e->dev.flags = 0;
     e->foreign_streams = true;  // the launch goes to a stream of the caller's (api_editor_quiesce)

@@ -702,6 +702,43 @@ def test_tile_entry_point_with_many_masks(gpu):
     assert_parity(d_out.cpu().numpy(), want)
 
 
+def test_many_mask_band_launch_leaves_an_rgb_editors_image_alone(gpu):
+    """An RGB editor's d_original is its IMAGE.  rpf_dev_develop with more than 16 masks needs a linear intermediate of the band: it
+    must be a buffer of its own — the editor's next apply_adjustments still renders the photo it was given."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(808)
+    h, w, n = 28, 60, 18
+    img = rng.random((h, w, 3), dtype=np.float32)
+    rgba = np.concatenate([img, np.ones((h, w, 1), np.float32)], -1)
+    params = [util.random_params(rng, trivial_prob=0.5) for _ in range(n)]
+    for p in params:
+        p.lens_distortion = 0
+    masks = np.ones((n, h, w), np.float32)
+    ed = R.PhotoEditor.new_from_rgb_f32(gpu, img, h, w)
+    for m in range(1, n):
+        mm = (rng.random((h, w)) > 0.6).astype(np.float32)
+        ed.add_mask(f"m{m}", mm)
+        masks[m] = O.binarize_mask(mm)
+    for m, p in enumerate(params):
+        util.configure_editor(ed, p, None if m == 0 else f"m{m}", main=(m == 0))
+    want = O.apply(rgba, params, masks=masks)
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), want)
+    cfa = util.bayer_natural(h, w, seed=808)
+    rp = util.raw_params()
+    band = np.zeros((h + 4, w), np.uint16)
+    band[2:-2] = cfa
+    d_band = torch.from_numpy(band.view(np.int16)).cuda()
+    d_out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    ed.dev_develop(d_band.data_ptr(), util.to_raw(rp), d_out.data_ptr(), R.OUT_RGBA_F32, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert_parity(d_out.cpu().numpy(), O.develop(cfa, rp, params, masks=masks))
+    ed.set_vignette(0 if params[0].vignette else 10)   # any state change: the next apply really launches again
+    ed.set_vignette(params[0].vignette)
+    ed.apply_adjustments()
+    assert_parity(ed.rgba(), want)
+
+
 def test_editors_share_a_processor_and_interleave(gpu):
     """One GpuProcessor, several editors on their own streams (the reference's 3-editor preview pyramid,
     Arc<GpuProcessor>, lib.rs:83): interleaved setters / applies / readbacks stay independent."""
