@@ -35,11 +35,84 @@ BYTES_PER_PX = {"develop": 18, "batch": 18, "demosaic": 18, "apply": 32,   # SUR
                 "develop_packed": 17.75}                        # 14-bit packed in (1.75 B) + RGBA32F out
 
 
+# The card's shader clock and socket power while the timed region runs (hwmon freq1_input / power1_input of the card's sysfs
+# node): the fused kernels are bound by VALU issue, so their time scales with the clock the power limit leaves them — which
+# differs by ~5 % between boxes of one pool.  Sampled by a CHILD process that only reads two files (no GIL shared with the launch
+# loop, no GPU touched), time-stamped with CLOCK_MONOTONIC like the region's ends.
+_CLOCK_SAMPLER = r"""
+import sys, time
+paths = sys.argv[1:]
+try:
+    while True:
+        t = time.monotonic()
+        vals = []
+        for p in paths:
+            try:
+                with open(p) as f:
+                    vals.append(f.read().strip() or "-")
+            except OSError:
+                vals.append("-")
+        sys.stdout.write("%.6f %s\n" % (t, " ".join(vals)))
+        sys.stdout.flush()
+        time.sleep(0.001)
+except (BrokenPipeError, KeyboardInterrupt):
+    pass
+"""
+
+
+def start_clock_sampler(pci_bus_id):
+    """(process, None) or (None, reason): the sampler on the hwmon node of the card at `pci_bus_id`."""
+    import glob
+    import subprocess
+    try:
+        for dev in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(dev)).lower() != pci_bus_id.lower():
+                continue
+            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                f, p = os.path.join(hw, "freq1_input"), os.path.join(hw, "power1_input")
+                if os.access(f, os.R_OK):
+                    return subprocess.Popen([sys.executable, "-c", _CLOCK_SAMPLER, f, p if os.access(p, os.R_OK) else "/nonexistent"],
+                                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True), None
+        return None, "no readable hwmon freq1_input for " + pci_bus_id
+    except OSError as ex:
+        return None, str(ex)
+
+
+def stop_clock_sampler(proc, t_begin, t_end):
+    """Median / min shader clock (MHz) and median power (W) of the samples inside [t_begin, t_end] (CLOCK_MONOTONIC); when the
+    region is shorter than a few samples, of the 50 ms that end with it (preheat and warm-up run the same kernel)."""
+    import statistics
+    proc.terminate()
+    try:
+        text = proc.communicate(timeout=5)[0]
+    except Exception:
+        proc.kill()
+        return None
+    rows = []
+    for line in text.splitlines():
+        parts = line.split()
+        if len(parts) == 3 and parts[1].isdigit():
+            rows.append((float(parts[0]), int(parts[1]) / 1e6, int(parts[2]) / 1e6 if parts[2].isdigit() else None))
+    inside = [r for r in rows if t_begin <= r[0] <= t_end]
+    window = "the timed region"
+    if len(inside) < 5:
+        inside = [r for r in rows if t_end - 0.05 <= r[0] <= t_end]
+        window = "the 50 ms that end with the timed region (preheat / warm-up launches of the same kernel included)"
+    if not inside:
+        return None
+    mhz = [r[1] for r in inside]
+    watts = [r[2] for r in inside if r[2] is not None]
+    return {"sclk_mhz_median": round(statistics.median(mhz), 1), "sclk_mhz_min": round(min(mhz), 1), "sclk_mhz_max": round(max(mhz), 1),
+            "power_w_median": round(statistics.median(watts), 1) if watts else None, "samples": len(inside), "window": window,
+            "source": "hwmon freq1_input / power1_input of the card, read every ~1 ms by a child process"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-clocks", action="store_true", help="do not sample the card's shader clock and power (roofline.clocks)")
     ap.add_argument("--preheat", type=int, default=1000,
                     help="untimed steps before the W warmup steps (same count on every rank): an idle MI355X needs "
                          "~50 launches (15 ms) to reach its clocks and a few hundred more to settle (a 20-step timed region "
@@ -347,6 +420,17 @@ def main():
             shard.drain(stream)
         torch.cuda.synchronize()
 
+    sampler = None
+    if rank == 0 and not args.no_clocks:
+        try:
+            _p = torch.cuda.get_device_properties(local)
+            sampler, _ = start_clock_sampler("%04x:%02x:%02x.0" % (getattr(_p, "pci_domain_id", 0), getattr(_p, "pci_bus_id", 0),
+                                                                   getattr(_p, "pci_device_id", 0)))
+        except Exception:   # a figure beside the measurement, never a reason to lose it
+            sampler = None
+        if sampler is not None:   # whatever ends this run early, the child does not outlive it
+            import atexit
+            atexit.register(lambda p=sampler: p.poll() is None and p.kill())
     preheat_steps = max(0, args.preheat)
     for _ in range(preheat_steps):
         step()
@@ -361,10 +445,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t0_mono = time.monotonic()
     for i in range(args.steps):
         step(i)
     drain()                                # this rank's K steps are done (device-wide synchronise inside)
     dt = time.perf_counter() - t0          # the job's time is the MAX of these over the ranks (below): the closing barrier
+    clocks = stop_clock_sampler(sampler, t0_mono, time.monotonic()) if sampler is not None else None
     if world > 1:                          # brackets the region but its own latency (a collective: ~0.1 ms, a fifth of 20
         dist.barrier()                     # steps on a 500-row band) is not part of any rank's K steps
     torch.cuda.synchronize()
@@ -515,6 +601,8 @@ def main():
                      "kernel_ms_avg": round(kern_avg_ms, 4), "bytes_per_px": bpp},
     }
 
+    if clocks:
+        result["roofline"]["clocks"] = clocks
     # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 wraps
     # the command): they come from the FETCH_SIZE / WRITE_SIZE passes of the same command, summarised by
     # tools/summarize_profiles.py into profiles/hbm_traffic.json (see profiles/*_summary.md).
@@ -527,7 +615,10 @@ def main():
             result["roofline"]["traffic_unit"] = "HBM bytes per launch (algorithmic: %d)" % (bpp * rows * W)
             result["roofline"]["traffic_source"] = tr["source"]
             if "valu" in tr:   # the secondary ceiling SURVEY.md §8(d) asks to report when frac < 0.7
-                result["roofline"]["valu"] = tr["valu"]
+                result["roofline"]["valu"] = dict(tr["valu"])
+                if clocks:   # at THIS run's kernel time and clock: cycles per wave-instruction per SIMD (1024 SIMDs)
+                    ns = kern_avg_ms * 1e6 * 1024 / tr["valu"]["wave_instructions_per_launch"]
+                    result["roofline"]["valu"]["cycles_per_instruction_per_simd_in_this_run"] = round(ns * clocks["sclk_mhz_median"] / 1e3, 3)
     except (OSError, ValueError):
         pass
 
