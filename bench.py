@@ -71,8 +71,11 @@ def start_clock_sampler(pci_bus_id):
             for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
                 f, p = os.path.join(hw, "freq1_input"), os.path.join(hw, "power1_input")
                 if os.access(f, os.R_OK):
+                    # (under rocprofv3 this process carries the profiler's preload: the child reads two files and needs none of it)
+                    env = {k: v for k, v in os.environ.items()
+                           if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
                     return subprocess.Popen([sys.executable, "-c", _CLOCK_SAMPLER, f, p if os.access(p, os.R_OK) else "/nonexistent"],
-                                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True), None
+                                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env), None
         return None, "no readable hwmon freq1_input for " + pci_bus_id
     except OSError as ex:
         return None, str(ex)
