@@ -20,6 +20,23 @@ for _ in range(6):
     rgb = rng.random((5000, 3), dtype=np.float32) * np.float32(1.3) - np.float32(0.1)
     img = np.concatenate([rgb, np.ones((5000, 1), np.float32)], 1).reshape(1, 5000, 4)
     assert np.array_equal(util.twin_apply(rgb, ps).view(np.uint32), O.apply(img, ps).reshape(5000, 4).view(np.uint32))
+# round 4: coverage planes past one word (edit_chain's WideMasks; plane counts on both sides of a boundary, a partial last plane)
+# and the binary32-only chain in both of its hue forms
+for n_masks in (2, 16, 17, 33):
+    ps = [util.random_params(rng, trivial_prob=0.4) for _ in range(n_masks)]
+    for p_ in ps:
+        p_.vignette = 0
+        p_.lens_distortion = 0
+    npx = 777
+    rgb = rng.random((npx, 3), dtype=np.float32)
+    masks = np.ones((n_masks, 1, npx), np.float32)
+    for m in range(1, n_masks):
+        masks[m, 0] = (rng.random(npx) > 0.5).astype(np.float32)
+    img = np.concatenate([rgb, np.ones((npx, 1), np.float32)], 1).reshape(1, npx, 4)
+    assert np.array_equal(util.twin_apply_masked(rgb, ps, masks).view(np.uint32), O.apply(img, ps, masks=masks).reshape(npx, 4).view(np.uint32))
+for fast in (True, "builtins"):
+    util.twin_apply(rng.random((3000, 3), dtype=np.float32), [util.params_S(), util.params_G()], fast=fast)
+    util.twin_apply(rng.random((3000, 3), dtype=np.float32), [util.params_G()], fast=fast)
 for shp in ((3, 3), (5, 8), (33, 47)):
     for pat in range(4):
         O.develop(util.bayer_uniform(*shp), O.RawParams(cfa_pattern=pat), [util.params_S()])
