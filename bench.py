@@ -81,26 +81,31 @@ def start_clock_sampler(pci_bus_id):
         return None, str(ex)
 
 
-def stop_clock_sampler(proc, t_begin, t_end):
-    """Median / min shader clock (MHz) and median power (W) of the samples inside [t_begin, t_end] (CLOCK_MONOTONIC); when the
-    region is shorter than a few samples, of the 50 ms that end with it (preheat and warm-up run the same kernel)."""
-    import statistics
+def stop_clock_sampler(proc):
+    """Ends the sampler; its samples as (CLOCK_MONOTONIC seconds, MHz, W or None)."""
     proc.terminate()
     try:
         text = proc.communicate(timeout=5)[0]
     except Exception:
         proc.kill()
-        return None
+        return []
     rows = []
     for line in text.splitlines():
         parts = line.split()
         if len(parts) == 3 and parts[1].isdigit():
             rows.append((float(parts[0]), int(parts[1]) / 1e6, int(parts[2]) / 1e6 if parts[2].isdigit() else None))
+    return rows
+
+
+def clocks_between(rows, t_begin, t_end):
+    """Median / min / max shader clock (MHz) and median power (W) of the samples inside [t_begin, t_end] (CLOCK_MONOTONIC); when
+    the region is shorter than a few samples, of the 50 ms that end with it (the launches before it run the same kernel)."""
+    import statistics
     inside = [r for r in rows if t_begin <= r[0] <= t_end]
     window = "the timed region"
     if len(inside) < 5:
         inside = [r for r in rows if t_end - 0.05 <= r[0] <= t_end]
-        window = "the 50 ms that end with the timed region (preheat / warm-up launches of the same kernel included)"
+        window = "the 50 ms that end with the timed region (the launches before it, of the same kernel, included)"
     if not inside:
         return None
     mhz = [r[1] for r in inside]
@@ -453,7 +458,11 @@ def main():
         step(i)
     drain()                                # this rank's K steps are done (device-wide synchronise inside)
     dt = time.perf_counter() - t0          # the job's time is the MAX of these over the ranks (below): the closing barrier
-    clocks = stop_clock_sampler(sampler, t0_mono, time.monotonic()) if sampler is not None else None
+    t_head = (t0_mono, time.monotonic())
+    # The sampler ends with the timed region.  (Its readings during the `secondary` legs were tried and are not reported: the
+    # sensors average over a window, and after the host-side pauses between those short legs they showed 2333 MHz at 337 W for
+    # a leg that ran slower than at 1940 — only a reading after ~0.2 s of continuous load, as here, is the kernel's clock.)
+    samples = stop_clock_sampler(sampler) if sampler is not None else []
     if world > 1:                          # brackets the region but its own latency (a collective: ~0.1 ms, a fifth of 20
         dist.barrier()                     # steps on a 500-row band) is not part of any rank's K steps
     torch.cuda.synchronize()
@@ -604,8 +613,6 @@ def main():
                      "kernel_ms_avg": round(kern_avg_ms, 4), "bytes_per_px": bpp},
     }
 
-    if clocks:
-        result["roofline"]["clocks"] = clocks
     # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 wraps
     # the command): they come from the FETCH_SIZE / WRITE_SIZE passes of the same command, summarised by
     # tools/summarize_profiles.py into profiles/hbm_traffic.json (see profiles/*_summary.md).
@@ -619,9 +626,6 @@ def main():
             result["roofline"]["traffic_source"] = tr["source"]
             if "valu" in tr:   # the secondary ceiling SURVEY.md §8(d) asks to report when frac < 0.7
                 result["roofline"]["valu"] = dict(tr["valu"])
-                if clocks:   # at THIS run's kernel time and clock: cycles per wave-instruction per SIMD (1024 SIMDs)
-                    ns = kern_avg_ms * 1e6 * 1024 / tr["valu"]["wave_instructions_per_launch"]
-                    result["roofline"]["valu"]["cycles_per_instruction_per_simd_in_this_run"] = round(ns * clocks["sclk_mhz_median"] / 1e3, 3)
     except (OSError, ValueError):
         pass
 
@@ -705,6 +709,15 @@ def main():
         }
         del frames
         result["secondary"] = sec
+
+    # the card's clock and power during the headline's timed region
+    c = clocks_between(samples, *t_head) if samples else None
+    if c:
+        result["roofline"]["clocks"] = c
+        v = result["roofline"].get("valu")
+        if v and v.get("wave_instructions_per_launch"):   # at THIS run's kernel time and clock: cycles per wave-instruction per SIMD
+            ns = kern_avg_ms * 1e6 * 1024 / v["wave_instructions_per_launch"]
+            v["cycles_per_instruction_per_simd_in_this_run"] = round(ns * c["sclk_mhz_median"] / 1e3, 3)
 
     if rank == 0 and world == 1 and not rehearse and not args.no_cpu_baseline:
         import oracle as O   # the checker, timed as the reported CPU baseline (never on the GPU path)
