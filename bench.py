@@ -637,7 +637,7 @@ def main():
         nsec = max(8, args.secondary_steps)
 
         def timed(fn, n):
-            for _ in range(20):
+            for _ in range(300):   # ~50 ms of the leg's own kernel first: the clock it will be measured at (cf. --preheat)
                 fn()
             torch.cuda.synchronize()
             pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
