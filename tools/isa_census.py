@@ -97,11 +97,14 @@ def census(path, name):
     lines = open(path).read().splitlines()
     body = kernel_body(lines, name)
     lo, hi = innermost_loop(body)
-    # the compiler places the loop's latch block (window slide) in front of the header: include it
+    # the compiler may place the loop's latch block (window slide) in front of the header: include it — but only a block that
+    # names THIS loop's header (the block in front of k_hp's step loop is the work item's prologue, a block of the outer loop:
+    # counting it added 143 instructions per trip to every total of that kernel until round 4)
+    header = body[lo].split(":")[0].strip().lstrip(".L")
     k = lo - 1
     while k > 0 and not body[k].startswith(".LBB"):
         k -= 1
-    if k > 0 and "in Loop" in body[k]:
+    if k > 0 and ("Header=" + header) in body[k].replace(" ", ""):
         lo = k
     # split into basic blocks at labels; drop blocks with v_sqrt_f32 (the IEEE fallback of sqrt_cr)
     blocks, cur = [], []
